@@ -1,0 +1,819 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see ge_oracle.h.  CPU restatement of the reference hot path.
+ * Every function cites the reference (file:line under /root/reference/graph_envs/) or the
+ * third-party source it restates ([nx] = networkx 3.4.2, [np] = numpy 2.2.6 legacy
+ * RandomState, [py] = CPython 3.10 random, [sp] = scipy 1.15.3 sparse).
+ */
+#include "ge_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ MT19937 */
+/* [py] Modules/_randommodule.c genrand_uint32 / init_genrand / init_by_array;
+ * [np] numpy/random/src/mt19937/mt19937.c (same generator). state[624] = index. */
+#define MT_N 624
+#define MT_M 397
+
+static void mt_init_genrand(uint32_t *mt, uint32_t s) {
+  mt[0] = s;
+  for (int i = 1; i < MT_N; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  mt[MT_N] = MT_N;
+}
+
+static void mt_init_by_array(uint32_t *mt, const uint32_t *key, int klen) {
+  mt_init_genrand(mt, 19650218u);
+  int i = 1, j = 0;
+  int k = (MT_N > klen) ? MT_N : klen;
+  for (; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+    i++; j++;
+    if (i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+    if (j >= klen) j = 0;
+  }
+  for (k = MT_N - 1; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    i++;
+    if (i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+  mt[MT_N] = MT_N;
+}
+
+static uint32_t mt_next(uint32_t *mt) {
+  if (mt[MT_N] >= MT_N) {
+    int kk;
+    for (kk = 0; kk < MT_N - MT_M; kk++) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + MT_M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; kk < MT_N - 1; kk++) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + (MT_M - MT_N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    uint32_t y = (mt[MT_N - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[MT_N - 1] = mt[MT_M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    mt[MT_N] = 0;
+  }
+  uint32_t y = mt[mt[MT_N]++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+void oge_mt_py_seed(uint32_t *st, uint32_t seed) { mt_init_by_array(st, &seed, 1); }
+void oge_mt_np_seed(uint32_t *st, uint32_t seed) { mt_init_genrand(st, seed); }
+uint32_t oge_mt_next(uint32_t *st) { return mt_next(st); }
+
+static int bit_length(uint32_t v) { int k = 0; while (v) { k++; v >>= 1; } return k; }
+
+/* [py] Lib/random.py:_randbelow_with_getrandbits; getrandbits(k<=32) = genrand >> (32-k) */
+static uint32_t py_randbelow(uint32_t *mt, uint32_t n) {
+  int k = bit_length(n);
+  uint32_t r = mt_next(mt) >> (32 - k);
+  while (r >= n) r = mt_next(mt) >> (32 - k);
+  return r;
+}
+
+/* [np] distributions.c buffered_bounded_masked_uint32 (legacy randint, masked rejection) */
+static int64_t np_randint(uint32_t *mt, int64_t low, int64_t high) {
+  uint32_t rng = (uint32_t)(high - 1 - low);
+  if (rng == 0) return low; /* no draw consumed */
+  uint32_t mask = rng;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  uint32_t v;
+  while ((v = (mt_next(mt) & mask)) > rng) {}
+  return low + (int64_t)v;
+}
+
+/* [np] legacy-distributions / mtrand.pyx _shuffle_raw -> random_interval */
+static uint32_t np_interval(uint32_t *mt, uint32_t max) {
+  if (max == 0) return 0;
+  uint32_t mask = max;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  uint32_t v;
+  while ((v = (mt_next(mt) & mask)) > max) {}
+  return v;
+}
+
+/* [np] mt19937_next_double: 53-bit resolution */
+static double np_rand(uint32_t *mt) {
+  int32_t a = (int32_t)(mt_next(mt) >> 5), b = (int32_t)(mt_next(mt) >> 6);
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* ------------------------------------------------------------------ env */
+struct oge_env {
+  oge_cfg cfg;
+  int n, m, E, F, Fe, A, nflag;
+  uint32_t py[MT_N + 1], np[MT_N + 1];
+  /* undirected graph in insertion order */
+  int *ucnt, *uadj;     /* uadj[u*n + k] */
+  uint8_t *has;         /* n*n */
+  double *uw;           /* n*n undirected weight by (u,v) */
+  /* directed CSR (row = source, insertion-order columns) */
+  int *row_ptr, *col;
+  double *w64;          /* per directed edge */
+  double *adjw;         /* dense n*n f64 == reference self.adj */
+  uint8_t *adjm;        /* dense adjacency flags */
+  float *x, *ef;
+  int64_t *links;
+  uint8_t *mask;
+  double *sf64;
+  int head, src, dest, start;
+  int *terms; int n_targets; /* terms[0]=src, terms[1..n_targets] */
+  double cost64; float cost32;
+  double heuristic;
+  int64_t edge_taken_cnt; int nodes_taken_cnt;
+  uint8_t *alive; int n_alive; /* residual graph for parenting >= 2 */
+  uint8_t *dtaken;             /* densest: python set nodes_taken */
+  double n_choices;
+  /* scratch */
+  int *q, *dist, *stk, *pred_ptr, *pred;
+  double *sigma, *delta, *bc, *pr_x, *pr_new, *pr_data, *pr_sinv;
+  int *scol; double *sw;
+  uint8_t *tmp8;
+};
+
+static int node_flag_count(int t) { return t == OGE_TSP ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : 2); }
+
+int oge_num_node_features(const oge_env *e) { return e->F; }
+int oge_num_edge_features(const oge_env *e) { return e->Fe; }
+int oge_num_directed_edges(const oge_env *e) { return e->E; }
+int oge_mask_size(const oge_env *e) { return e->A; }
+int oge_obs_size(const oge_env *e) { return e->n * e->F + e->E * e->Fe + 2 * e->E; }
+
+oge_env *oge_create(const oge_cfg *cfg) {
+  oge_env *e = (oge_env *)calloc(1, sizeof(oge_env));
+  e->cfg = *cfg;
+  int n = cfg->n_nodes, m = cfg->n_edges;
+  e->n = n; e->m = m; e->E = 2 * m;
+  e->nflag = node_flag_count(cfg->env_type);
+  e->F = e->nflag + 5;                                   /* utils.py:32-73 (+5 :72) */
+  e->Fe = (cfg->env_type == OGE_STEINER_TREE) ? 2 : 1;   /* utils.py:37-40 */
+  e->A = (cfg->env_type == OGE_STEINER_TREE) ? e->E : n; /* steiner_tree.py:117 */
+  /* densest_subgraph.py:38-39: n_choices = n_nodes // e (float floor division) */
+  e->n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;
+  size_t nn = (size_t)n * n;
+  e->ucnt = calloc(n, sizeof(int)); e->uadj = calloc(nn, sizeof(int));
+  e->has = calloc(nn, 1); e->uw = calloc(nn, sizeof(double));
+  e->row_ptr = calloc(n + 1, sizeof(int)); e->col = calloc(e->E + 1, sizeof(int));
+  e->w64 = calloc(e->E + 1, sizeof(double)); e->adjw = calloc(nn, sizeof(double));
+  e->adjm = calloc(nn, 1);
+  e->x = calloc((size_t)n * e->F, sizeof(float)); e->ef = calloc((size_t)e->E * e->Fe + 1, sizeof(float));
+  e->links = calloc((size_t)2 * e->E + 2, sizeof(int64_t));
+  e->mask = calloc(e->A + 1, 1); e->sf64 = calloc((size_t)n * 5, sizeof(double));
+  e->terms = calloc(n + 1, sizeof(int));
+  e->alive = calloc(n, 1); e->dtaken = calloc(n, 1);
+  e->q = calloc(n, sizeof(int)); e->dist = calloc(n, sizeof(int)); e->stk = calloc(n, sizeof(int));
+  e->pred_ptr = calloc(n + 1, sizeof(int)); e->pred = calloc(e->E + 1, sizeof(int));
+  e->sigma = calloc(n, sizeof(double)); e->delta = calloc(n, sizeof(double)); e->bc = calloc(n, sizeof(double));
+  e->pr_x = calloc(n, sizeof(double)); e->pr_new = calloc(n, sizeof(double));
+  e->pr_data = calloc(e->E + 1, sizeof(double)); e->pr_sinv = calloc(n, sizeof(double));
+  e->scol = calloc(n, sizeof(int)); e->sw = calloc(n, sizeof(double)); e->tmp8 = calloc(n, 1);
+  e->py[MT_N] = MT_N; e->np[MT_N] = MT_N;
+  mt_init_by_array(e->py, (const uint32_t[]){0u}, 1);
+  mt_init_genrand(e->np, 0u);
+  return e;
+}
+
+void oge_destroy(oge_env *e) {
+  if (!e) return;
+  free(e->ucnt); free(e->uadj); free(e->has); free(e->uw); free(e->row_ptr); free(e->col);
+  free(e->w64); free(e->adjw); free(e->adjm); free(e->x); free(e->ef); free(e->links); free(e->mask);
+  free(e->sf64); free(e->terms); free(e->alive); free(e->dtaken); free(e->q); free(e->dist);
+  free(e->stk); free(e->pred_ptr); free(e->pred); free(e->sigma); free(e->delta); free(e->bc);
+  free(e->pr_x); free(e->pr_new); free(e->pr_data); free(e->pr_sinv); free(e->scol); free(e->sw);
+  free(e->tmp8); free(e);
+}
+
+/* ------------------------------------------------------------------ graph sampling */
+/* [nx] generators/random_graphs.py:257-309 gnm_random_graph on ng nodes (nodes ng..n-1 stay isolated) */
+static void gnm_random_graph(oge_env *e, int ng, int m) {
+  int n = e->n;
+  memset(e->ucnt, 0, n * sizeof(int));
+  memset(e->has, 0, (size_t)n * n);
+  if (ng == 1) return;
+  double max_edges = ng * (ng - 1) / 2.0;
+  if (m >= max_edges) { /* complete_graph: itertools.combinations order -> sorted rows */
+    for (int u = 0; u < ng; u++)
+      for (int v = u + 1; v < ng; v++) {
+        e->uadj[u * n + e->ucnt[u]++] = v; e->uadj[v * n + e->ucnt[v]++] = u;
+        e->has[u * n + v] = e->has[v * n + u] = 1;
+      }
+    return;
+  }
+  int cnt = 0;
+  while (cnt < m) {
+    int u = (int)py_randbelow(e->py, (uint32_t)ng);
+    int v = (int)py_randbelow(e->py, (uint32_t)ng);
+    if (u == v || e->has[u * n + v]) continue;
+    e->uadj[u * n + e->ucnt[u]++] = v; e->uadj[v * n + e->ucnt[v]++] = u;
+    e->has[u * n + v] = e->has[v * n + u] = 1;
+    cnt++;
+  }
+}
+
+/* [nx] components/connected.py is_connected over the nodes [0,ng) minus `skip` (skip<0: none) */
+static int is_connected_u(oge_env *e, int ng, int skip) {
+  int n = e->n, start = (skip == 0) ? 1 : 0, total = ng - (skip >= 0 ? 1 : 0);
+  if (total <= 0) return 1;
+  memset(e->tmp8, 0, n);
+  int qh = 0, qt = 0, seen = 1;
+  e->q[qt++] = start; e->tmp8[start] = 1;
+  while (qh < qt) {
+    int v = e->q[qh++];
+    for (int k = 0; k < e->ucnt[v]; k++) {
+      int w = e->uadj[v * n + k];
+      if (w == skip || e->tmp8[w]) continue;
+      e->tmp8[w] = 1; seen++; e->q[qt++] = w;
+    }
+  }
+  return seen == total;
+}
+
+/* Graph.to_directed(): rows by source in node order, columns in undirected insertion order
+ *  -> CSR, edge_links, dense adj */
+static void build_directed(oge_env *e) {
+  int n = e->n, p = 0;
+  memset(e->adjw, 0, (size_t)n * n * sizeof(double));
+  memset(e->adjm, 0, (size_t)n * n);
+  for (int u = 0; u < n; u++) {
+    e->row_ptr[u] = p;
+    for (int k = 0; k < e->ucnt[u]; k++) {
+      int v = e->uadj[u * n + k];
+      e->col[p] = v; e->w64[p] = e->uw[u * n + v];
+      e->links[2 * p] = u; e->links[2 * p + 1] = v;
+      e->adjw[u * n + v] = e->w64[p]; e->adjm[u * n + v] = 1;
+      p++;
+    }
+  }
+  e->row_ptr[n] = p;
+}
+
+/* ------------------------------------------------------------------ structural features */
+/* numpy pairwise summation (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum) */
+static double np_pairwise_sum(const double *a, int n) {
+  if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += a[i]; return r; }
+  if (n <= 128) {
+    double r[8]; int i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+  }
+  int n2 = n / 2; n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* feature_extraction.py:6-37 on the directed symmetric graph; `pr_weighted`: TSP edges carry the
+ * attr 'weight' that nx.pagerank picks up by default (tsp.py:90), others use 'delay' -> weight 1 */
+static void generate_features(oge_env *e, int pr_weighted) {
+  int n = e->n;
+  const int *rp = e->row_ptr, *col = e->col;
+  double *sf = e->sf64;
+  /* degree: DiGraph.degree = in + out */
+  for (int v = 0; v < n; v++) sf[v * 5 + 0] = 2.0 * (rp[v + 1] - rp[v]);
+
+  /* [nx] centrality/betweenness.py betweenness_centrality (BFS Brandes, normalized, directed) */
+  for (int v = 0; v < n; v++) e->bc[v] = 0.0;
+  for (int s = 0; s < n; s++) {
+    int ns = 0, qh = 0, qt = 0;
+    for (int v = 0; v < n; v++) { e->sigma[v] = 0.0; e->dist[v] = -1; e->pred_ptr[v] = 0; }
+    /* predecessor lists: pred slots of w live at pred[rp[w] .. ) (|P[w]| <= indeg = outdeg) */
+    e->sigma[s] = 1.0; e->dist[s] = 0; e->q[qt++] = s;
+    while (qh < qt) {
+      int v = e->q[qh++]; e->stk[ns++] = v;
+      int dv = e->dist[v]; double sv = e->sigma[v];
+      for (int k = rp[v]; k < rp[v + 1]; k++) {
+        int w = col[k];
+        if (e->dist[w] < 0) { e->q[qt++] = w; e->dist[w] = dv + 1; }
+        if (e->dist[w] == dv + 1) { e->sigma[w] += sv; e->pred[rp[w] + e->pred_ptr[w]++] = v; }
+      }
+    }
+    for (int i = 0; i < ns; i++) e->delta[e->stk[i]] = 0.0;
+    while (ns) { /* _accumulate_basic */
+      int w = e->stk[--ns];
+      double coeff = (1.0 + e->delta[w]) / e->sigma[w];
+      for (int k = 0; k < e->pred_ptr[w]; k++) { int v = e->pred[rp[w] + k]; e->delta[v] += e->sigma[v] * coeff; }
+      if (w != s) e->bc[w] += e->delta[w];
+    }
+  }
+  if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (n - 2)); for (int v = 0; v < n; v++) e->bc[v] *= scale; }
+  for (int v = 0; v < n; v++) sf[v * 5 + 1] = e->bc[v];
+
+  /* [nx] centrality/closeness.py closeness_centrality (reverse graph == same graph, wf_improved) */
+  for (int s = 0; s < n; s++) {
+    int qh = 0, qt = 0; int64_t tot = 0;
+    for (int v = 0; v < n; v++) e->dist[v] = -1;
+    e->dist[s] = 0; e->q[qt++] = s;
+    while (qh < qt) {
+      int v = e->q[qh++]; tot += e->dist[v];
+      for (int k = rp[v]; k < rp[v + 1]; k++) { int w = col[k]; if (e->dist[w] < 0) { e->dist[w] = e->dist[v] + 1; e->q[qt++] = w; } }
+    }
+    double c = 0.0;
+    if (tot > 0 && n > 1) {
+      c = ((double)qt - 1.0) / (double)tot;
+      double sc = ((double)qt - 1.0) / (double)(n - 1);
+      c *= sc;
+    }
+    sf[s * 5 + 2] = c;
+  }
+
+  /* [nx] link_analysis/pagerank_alg.py _pagerank_scipy; [sp] csr row sums over sorted columns,
+   * x @ A == csc_matvec over source rows ascending */
+  {
+    const double alpha = 0.85, tol = 1.0e-6;
+    for (int i = 0; i < n; i++) {
+      int d = rp[i + 1] - rp[i];
+      for (int k = 0; k < d; k++) { e->scol[k] = col[rp[i] + k]; e->sw[k] = pr_weighted ? e->w64[rp[i] + k] : 1.0; }
+      for (int a = 1; a < d; a++) { /* insertion sort by column (canonical CSR) */
+        int c = e->scol[a]; double w = e->sw[a]; int b = a - 1;
+        while (b >= 0 && e->scol[b] > c) { e->scol[b + 1] = e->scol[b]; e->sw[b + 1] = e->sw[b]; b--; }
+        e->scol[b + 1] = c; e->sw[b + 1] = w;
+      }
+      double S = 0.0;
+      for (int k = 0; k < d; k++) S += e->sw[k] * 1.0;
+      e->pr_sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
+      for (int k = 0; k < d; k++) e->pr_data[rp[i] + k] = e->pr_sinv[i] * (pr_weighted ? e->w64[rp[i] + k] : 1.0);
+    }
+    double p = 1.0 / n; /* np.repeat(1.0 / N, N) */
+    for (int i = 0; i < n; i++) e->pr_x[i] = p;
+    double one_minus_alpha = 1 - alpha;
+    int converged = 0;
+    for (int it = 0; it < 100 && !converged; it++) {
+      for (int i = 0; i < n; i++) e->pr_new[i] = 0.0;
+      for (int j = 0; j < n; j++)
+        for (int k = rp[j]; k < rp[j + 1]; k++) e->pr_new[col[k]] += e->pr_data[k] * e->pr_x[j];
+      double dsum = 0.0; int any_d = 0;
+      for (int i = 0; i < n; i++) if (rp[i + 1] == rp[i]) { dsum = any_d ? dsum + e->pr_x[i] : e->pr_x[i]; any_d = 1; }
+      for (int i = 0; i < n; i++) e->pr_new[i] = alpha * (e->pr_new[i] + dsum * p) + one_minus_alpha * p;
+      for (int i = 0; i < n; i++) e->delta[i] = fabs(e->pr_new[i] - e->pr_x[i]);
+      double err = np_pairwise_sum(e->delta, n);
+      for (int i = 0; i < n; i++) e->pr_x[i] = e->pr_new[i];
+      if (err < n * tol) converged = 1;
+    }
+    for (int v = 0; v < n; v++) sf[v * 5 + 3] = converged ? e->pr_x[v] : NAN; /* reference raises */
+  }
+
+  /* [nx] cluster.py clustering (directed, unweighted): t / ((dt*(dt-1) - 2*db) * 2) */
+  for (int i = 0; i < n; i++) {
+    int64_t d = rp[i + 1] - rp[i], common = 0;
+    for (int a = rp[i]; a < rp[i + 1]; a++) {
+      int j = col[a];
+      for (int b = rp[i]; b < rp[i + 1]; b++) if (e->adjm[j * n + col[b]]) common++;
+    }
+    int64_t t = 8 * common, dt = 2 * d, db = d;
+    sf[i * 5 + 4] = (t == 0) ? 0.0 : (double)t / (double)((dt * (dt - 1) - 2 * db) * 2);
+  }
+  /* sf = torch.tensor(sf) -> float32; x[:, -5:] = sf */
+  for (int v = 0; v < n; v++) for (int k = 0; k < 5; k++) e->x[v * e->F + e->nflag + k] = (float)sf[v * 5 + k];
+}
+
+/* ------------------------------------------------------------------ baselines */
+/* [nx] shortest_paths/weighted.py _dijkstra_multisource: d[u] = min_v fl(d[v] + w(v,u)).  IEEE addition
+ * is monotone, so the least fixpoint is independent of the visiting order. */
+static double dijkstra(oge_env *e, int s, int t) {
+  int n = e->n;
+  for (int v = 0; v < n; v++) { e->sigma[v] = INFINITY; e->tmp8[v] = 0; }
+  e->sigma[s] = 0.0;
+  for (;;) {
+    int v = -1; double best = INFINITY;
+    for (int u = 0; u < n; u++) if (!e->tmp8[u] && e->sigma[u] < best) { best = e->sigma[u]; v = u; }
+    if (v < 0) break;
+    e->tmp8[v] = 1;
+    if (v == t) break;
+    for (int k = e->row_ptr[v]; k < e->row_ptr[v + 1]; k++) {
+      int u = e->col[k]; double d = e->sigma[v] + e->w64[k];
+      if (d < e->sigma[u]) e->sigma[u] = d;
+    }
+  }
+  return e->sigma[t];
+}
+
+/* steiner_tree.py:80-81: sum(delay of nx.minimum_spanning_edges) = Kruskal order = ascending weights,
+ * python sum() left to right.  Prim picks the same weight multiset. */
+static double mst_total(oge_env *e) {
+  int n = e->n, cntw = 0;
+  double *key = e->sigma, *picked = e->delta;
+  for (int v = 0; v < n; v++) { key[v] = INFINITY; e->tmp8[v] = 0; }
+  key[0] = 0.0;
+  for (int it = 0; it < n; it++) {
+    int v = -1; double best = INFINITY;
+    for (int u = 0; u < n; u++) if (!e->tmp8[u] && key[u] < best) { best = key[u]; v = u; }
+    if (v < 0) break;
+    e->tmp8[v] = 1; if (it) picked[cntw++] = key[v];
+    for (int k = e->row_ptr[v]; k < e->row_ptr[v + 1]; k++) { int u = e->col[k]; if (!e->tmp8[u] && e->w64[k] < key[u]) key[u] = e->w64[k]; }
+  }
+  for (int a = 1; a < cntw; a++) { double w = picked[a]; int b = a - 1; while (b >= 0 && picked[b] > w) { picked[b + 1] = picked[b]; b--; } picked[b + 1] = w; }
+  double s = 0.0; /* python: 0 + w0 + w1 ... */
+  for (int a = 0; a < cntw; a++) s += picked[a];
+  return s;
+}
+
+/* ------------------------------------------------------------------ masks */
+/* BFS reach set from `from` inside alive nodes, optionally without `skip` */
+static int residual_reach(oge_env *e, int from, int skip, uint8_t *seen) {
+  int n = e->n, qh = 0, qt = 0, cnt = 1;
+  memset(seen, 0, n);
+  seen[from] = 1; e->q[qt++] = from;
+  while (qh < qt) {
+    int v = e->q[qh++];
+    for (int k = e->row_ptr[v]; k < e->row_ptr[v + 1]; k++) {
+      int w = e->col[k];
+      if (!e->alive[w] || w == skip || seen[w]) continue;
+      seen[w] = 1; cnt++; e->q[qt++] = w;
+    }
+  }
+  return cnt;
+}
+
+static void compute_mask(oge_env *e) {
+  int n = e->n, F = e->F;
+  switch (e->cfg.env_type) {
+    case OGE_SHORTEST_PATH: /* shortest_path.py:105-109 */
+      memset(e->mask, 0, n);
+      for (int k = e->row_ptr[e->head]; k < e->row_ptr[e->head + 1]; k++) e->mask[e->col[k]] = 1;
+      for (int v = 0; v < n; v++) if (e->x[v * F + 0] == 1.0f) e->mask[v] = 0;
+      break;
+    case OGE_LONGEST_PATH: /* longest_path.py:125-145 */
+      if (e->cfg.parenting == 0) { memset(e->mask, 1, n); break; }
+      memset(e->mask, 0, n);
+      for (int k = e->row_ptr[e->head]; k < e->row_ptr[e->head + 1]; k++) e->mask[e->col[k]] = 1;
+      for (int v = 0; v < n; v++) if (e->x[v * F + 0] == 1.0f) e->mask[v] = 0;
+      if (e->cfg.parenting >= 2) {
+        if (!e->alive[e->dest]) break;
+        residual_reach(e, e->dest, -1, e->tmp8); /* has_path(alt_G, k, dest), symmetric graph */
+        for (int v = 0; v < n; v++) if (e->mask[v] && !e->tmp8[v]) e->mask[v] = 0;
+        if (e->cfg.parenting == 3 && e->n_alive <= n / 3) for (int v = 0; v < n; v++) if (e->alive[v]) e->mask[v] = 1;
+      }
+      break;
+    case OGE_STEINER_TREE: /* steiner_tree.py:116-120 */
+      for (int p = 0; p < e->E; p++) {
+        int u = (int)e->links[2 * p], v = (int)e->links[2 * p + 1];
+        e->mask[p] = !(e->x[u * F + 0] < 0.5f) && !(e->x[v * F + 0] > 0.5f);
+      }
+      break;
+    case OGE_TSP: { /* tsp.py:174-199 */
+      memset(e->mask, 0, n);
+      for (int k = e->row_ptr[e->head]; k < e->row_ptr[e->head + 1]; k++) e->mask[e->col[k]] = 1;
+      float tsum = 0.f;
+      for (int v = 0; v < n; v++) { if (e->x[v * F + 0] == 1.0f) e->mask[v] = 0; tsum += e->x[v * F + 0]; }
+      if (tsum < (float)(n - 1)) e->mask[e->start] = 0;
+      if (e->cfg.parenting >= 2) {
+        for (int v = 0; v < n; v++) {
+          if (!e->mask[v] || v == e->start) continue;
+          /* G_copy = alt_G minus v */
+          int remaining = e->n_alive - (e->alive[v] ? 1 : 0);
+          if (remaining == 0) break;
+          int from = -1;
+          for (int u = 0; u < n; u++) if (e->alive[u] && u != v) { from = u; break; }
+          if (residual_reach(e, from, v, e->tmp8) != remaining) e->mask[v] = 0;
+        }
+      }
+      break;
+    }
+    case OGE_DENSEST_SUBGRAPH: { /* densest_subgraph.py:105-129 */
+      float tsum = 0.f;
+      for (int v = 0; v < n; v++) tsum += e->x[v * F + 0];
+      if (tsum == 0.f) { memset(e->mask, 1, n); break; }
+      if (e->cfg.parenting == 0) { for (int v = 0; v < n; v++) e->mask[v] = !(e->x[v * F + 0] == 1.0f); break; }
+      memset(e->mask, 0, n);
+      for (int p = 0; p < e->E; p++) if (e->x[e->links[2 * p] * F + 0] == 1.0f) e->mask[e->links[2 * p + 1]] = 1;
+      for (int v = 0; v < n; v++) if (e->x[v * F + 0] == 1.0f) e->mask[v] = 0;
+      break;
+    }
+    case OGE_MAX_INDEPENDENT_SET: /* max_independent_set.py:92-100 */
+      for (int v = 0; v < n; v++) e->mask[v] = (e->x[v * F + 1] == 0.0f);
+      break;
+  }
+}
+
+/* ------------------------------------------------------------------ reset */
+static void sample_terminals(oge_env *e, int k) { /* np.random.choice(n, k, replace=False) = permutation(n)[:k] */
+  int n = e->n;
+  for (int i = 0; i < n; i++) e->q[i] = i;
+  for (int i = n - 1; i >= 1; i--) { int j = (int)np_interval(e->np, (uint32_t)i); int t = e->q[i]; e->q[i] = e->q[j]; e->q[j] = t; }
+  for (int i = 0; i < k; i++) e->terms[i] = e->q[i];
+}
+
+static void delay_matrix_weights(oge_env *e) { /* shortest_path.py:59-67 */
+  int n = e->n;
+  if (e->cfg.weighted) {
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) e->uw[i * n + j] = (double)np_randint(e->np, 3, 10) / 10.0;
+  } else {
+    for (size_t i = 0; i < (size_t)n * n; i++) e->uw[i] = 1.0; /* randint(10,11)/10.0 or randint(1,2)/1.0: no draws */
+  }
+  /* for u, v, d in G.edges(data=True): d['delay'] = delay[u, v] with u < v */
+  for (int u = 0; u < n; u++) for (int v = u + 1; v < n; v++) e->uw[v * n + u] = e->uw[u * n + v];
+}
+
+int oge_reset(oge_env *e, int64_t seed) {
+  const int t = e->cfg.env_type;
+  int n = e->n, m = e->m, F = e->F, attempts = 0;
+  if (seed >= 0) { /* shortest_path.py:49-52 */
+    uint32_t s = (uint32_t)seed;
+    mt_init_by_array(e->py, &s, 1);
+    mt_init_genrand(e->np, s);
+  }
+  int ng = (t == OGE_DENSEST_SUBGRAPH) ? n - 1 : n; /* densest_subgraph.py:59-65 */
+  for (;;) {
+    attempts++;
+    gnm_random_graph(e, ng, m);
+    if (!is_connected_u(e, ng, -1)) continue;
+    if (t == OGE_TSP) { /* tsp.py:60-71 */
+      int bad = 0;
+      for (int v = 0; v < n; v++) if (e->ucnt[v] == 1) bad = 1;
+      if (bad) continue;
+      if (!is_connected_u(e, ng, 0)) continue;
+    }
+    break;
+  }
+  memset(e->x, 0, (size_t)n * F * sizeof(float));
+  e->n_targets = 0; e->heuristic = 0.0; e->cost64 = 0.0; e->cost32 = 0.0f;
+  e->edge_taken_cnt = 0; e->nodes_taken_cnt = 0; memset(e->dtaken, 0, n);
+  for (int v = 0; v < n; v++) e->alive[v] = 1;
+  e->n_alive = n;
+  int pr_weighted = 0;
+
+  if (t == OGE_SHORTEST_PATH || t == OGE_LONGEST_PATH) {
+    delay_matrix_weights(e);
+    build_directed(e);
+    sample_terminals(e, 2); /* shortest_path.py:74 */
+    e->src = e->terms[0]; e->dest = e->terms[1]; e->n_targets = 1;
+    e->x[e->src * F + 0] = 1.f; e->x[e->dest * F + 1] = 1.f;
+    if (t == OGE_LONGEST_PATH && e->cfg.parenting == 0) e->x[e->src * F + 1] = 2.f; /* longest_path.py:85-86 */
+    e->head = e->src;
+    if (t == OGE_LONGEST_PATH && e->cfg.parenting >= 2) { e->alive[e->src] = 0; e->n_alive--; }
+    for (int p = 0; p < e->E; p++) e->ef[p] = (float)e->w64[p];
+    if (e->cfg.is_eval_env) { double d = dijkstra(e, e->src, e->dest); e->heuristic = (t == OGE_LONGEST_PATH) ? -d : d; }
+  } else if (t == OGE_STEINER_TREE) {
+    delay_matrix_weights(e);
+    build_directed(e);
+    sample_terminals(e, e->cfg.n_dests + 1); /* steiner_tree.py:73 */
+    e->n_targets = e->cfg.n_dests; e->src = e->terms[0];
+    if (e->cfg.is_eval_env) { /* steiner_tree.py:77-85 */
+      if (e->cfg.n_dests == 1) e->heuristic = dijkstra(e, e->terms[0], e->terms[1]);
+      else if (e->cfg.n_dests == n - 1) e->heuristic = mst_total(e);
+      else e->heuristic = NAN; /* Kou: not restated */
+    }
+    e->x[e->src * F + 0] = 1.f;
+    for (int i = 1; i <= e->n_targets; i++) e->x[e->terms[i] * F + 1] = 1.f;
+    e->head = e->src;
+    for (int p = 0; p < e->E; p++) { e->ef[2 * p] = (float)e->w64[p]; e->ef[2 * p + 1] = 0.f; }
+  } else if (t == OGE_TSP) {
+    e->start = 0; e->src = 0;
+    double *px = e->sigma, *pyy = e->delta;
+    if (e->cfg.spatial) { /* tsp.py:79-86 */
+      for (int v = 0; v < n; v++) { px[v] = np_rand(e->np) * 10; pyy[v] = np_rand(e->np) * 10; }
+      for (int u = 0; u < n; u++) for (int k = 0; k < e->ucnt[u]; k++) {
+        int v = e->uadj[u * n + k]; if (v < u) continue;
+        double dx = px[u] - px[v], dy = pyy[u] - pyy[v];
+        double w = sqrt(dx * dx + dy * dy);
+        e->uw[u * n + v] = e->uw[v * n + u] = w;
+      }
+    } else { /* tsp.py:88-93: one scalar draw per undirected edge in G.edges order */
+      for (int u = 0; u < n; u++) for (int k = 0; k < e->ucnt[u]; k++) {
+        int v = e->uadj[u * n + k]; if (v < u) continue;
+        double w = e->cfg.weighted ? (double)np_randint(e->np, 3, 10) / 10.0 : 1.0;
+        e->uw[u * n + v] = e->uw[v * n + u] = w;
+      }
+    }
+    e->heuristic = e->cfg.is_eval_env ? NAN : 0.0; /* Christofides: not restated */
+    if (e->cfg.parenting >= 2) { e->alive[0] = 0; e->n_alive--; }
+    build_directed(e);
+    if (e->cfg.spatial) for (int v = 0; v < n; v++) { e->x[v * F + 2] = (float)px[v]; e->x[v * F + 3] = (float)pyy[v]; }
+    e->x[e->start * F + 1] = 1.f; e->head = e->start;
+    for (int p = 0; p < e->E; p++) e->ef[p] = (float)e->w64[p];
+    pr_weighted = 1;
+  } else if (t == OGE_DENSEST_SUBGRAPH) {
+    for (size_t i = 0; i < (size_t)n * n; i++) e->uw[i] = 1.0;
+    build_directed(e);
+    for (int p = 0; p < e->E; p++) e->ef[p] = 1.f;
+    e->heuristic = e->cfg.is_eval_env ? -1.0 : 0.0; e->head = -1;
+  } else { /* MIS: max_independent_set.py:53-60 */
+    double *cost = e->sigma;
+    for (int v = 0; v < n; v++) cost[v] = e->cfg.weighted ? (double)np_randint(e->np, 3, 10) / 10.0 : 1.0;
+    for (size_t i = 0; i < (size_t)n * n; i++) e->uw[i] = 1.0;
+    build_directed(e);
+    for (int v = 0; v < n; v++) e->x[v * F + 0] = (float)cost[v];
+    for (int p = 0; p < e->E; p++) e->ef[p] = 1.f;
+    e->heuristic = e->cfg.is_eval_env ? (e->cfg.weighted ? -1.0 : NAN) : 0.0; e->head = -1;
+  }
+  generate_features(e, pr_weighted);
+  compute_mask(e);
+  if (t == OGE_TSP) { /* tsp.py:154-155 */
+    int s = 0; for (int v = 0; v < n; v++) s += e->mask[v];
+    if (s == 0) e->mask[e->start] = 1;
+  }
+  return attempts;
+}
+
+int oge_inject(oge_env *e, const int64_t *links, const double *w64, const float *x,
+               const int32_t *terminals, int n_terminals) {
+  int n = e->n, F = e->F;
+  memset(e->ucnt, 0, n * sizeof(int)); memset(e->has, 0, (size_t)n * n);
+  for (int p = 0; p < e->E; p++) {
+    int u = (int)links[2 * p], v = (int)links[2 * p + 1];
+    if (u < 0 || u >= n || v < 0 || v >= n) return -1;
+    e->uadj[u * n + e->ucnt[u]++] = v; e->has[u * n + v] = 1; e->uw[u * n + v] = w64[p];
+  }
+  build_directed(e);
+  memcpy(e->x, x, (size_t)n * F * sizeof(float));
+  for (int i = 0; i < n_terminals; i++) e->terms[i] = terminals[i];
+  e->n_targets = n_terminals - 1; e->src = terminals[0]; e->dest = n_terminals > 1 ? terminals[1] : -1;
+  e->head = e->src; e->start = 0; e->cost64 = 0; e->cost32 = 0; e->heuristic = 0;
+  e->edge_taken_cnt = 0; e->nodes_taken_cnt = 0; memset(e->dtaken, 0, n);
+  for (int v = 0; v < n; v++) e->alive[v] = 1;
+  e->n_alive = n;
+  if ((e->cfg.env_type == OGE_LONGEST_PATH || e->cfg.env_type == OGE_TSP) && e->cfg.parenting >= 2) { e->alive[e->src] = 0; e->n_alive--; }
+  for (int p = 0; p < e->E; p++) { if (e->Fe == 2) { e->ef[2 * p] = (float)w64[p]; e->ef[2 * p + 1] = 0.f; } else e->ef[p] = (float)w64[p]; }
+  compute_mask(e);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ step */
+static int is_neighbor(const oge_env *e, int u, int v) { return e->adjm[u * e->n + v]; }
+static int mask_sum(const oge_env *e) { int s = 0; for (int i = 0; i < e->A; i++) s += e->mask[i]; return s; }
+
+int oge_step(oge_env *e, int64_t action, double *reward, int32_t *done, int32_t *solved) {
+  const int t = e->cfg.env_type;
+  int n = e->n, F = e->F;
+  *done = 0; *solved = -1; *reward = 0.0;
+  switch (t) {
+    case OGE_SHORTEST_PATH: { /* shortest_path.py:111-141 */
+      if (action < 0 || action >= n || !e->mask[action]) return OGE_INVALID_ACTION;
+      int a = (int)action;
+      double r = -e->adjw[e->head * n + a];
+      e->cost64 -= r;
+      if (e->x[a * F + 1] == 1.0f) { *done = 1; *solved = 1; }
+      e->x[a * F + 0] = 1.f; e->head = a;
+      compute_mask(e);
+      if (!*done && mask_sum(e) == 0) { *done = 1; r = -(double)n; *solved = 0; }
+      *reward = r;
+      return OGE_OK;
+    }
+    case OGE_LONGEST_PATH: { /* longest_path.py:147-196 */
+      if (action < 0 || action >= n || !e->mask[action]) return OGE_INVALID_ACTION;
+      int a = (int)action;
+      if (e->cfg.parenting >= 1 && (!is_neighbor(e, e->head, a) || e->x[a * F + 0] == 1.0f)) return OGE_INVALID_ACTION;
+      double r = e->adjw[e->head * n + a];
+      e->cost64 -= r;
+      if (!is_neighbor(e, e->head, a) || e->x[a * F + 0] == 1.0f) { /* :169-173, info has no mask */
+        *done = 1; *solved = 0; *reward = -2.0 * n; return OGE_OK;
+      }
+      e->head = a; e->x[a * F + 0] = 1.f;
+      if (e->x[a * F + 1] == 1.0f) { *done = 1; *solved = 1; }
+      if (e->cfg.parenting >= 2) { e->alive[a] = 0; e->n_alive--; }
+      compute_mask(e);
+      if (!*done && mask_sum(e) == 0) { *done = 1; r = -2.0 * n; *solved = 0; }
+      *reward = r;
+      return OGE_OK;
+    }
+    case OGE_STEINER_TREE: { /* steiner_tree.py:123-157 */
+      if (action < 0 || action >= e->E || !e->mask[action]) return OGE_INVALID_ACTION;
+      int v = (int)e->links[2 * action + 1];
+      float r = -e->ef[2 * action + 0];
+      e->cost32 -= r; /* python int 0 then numpy float32 accumulation */
+      e->x[v * F + 0] = 1.f;
+      int missing = 0;
+      for (int u = 0; u < n; u++) if (e->x[u * F + 0] == 0.f && e->x[u * F + 1] == 1.f) missing++;
+      if (missing == 0) { *done = 1; *solved = 1; }
+      compute_mask(e);
+      *reward = (double)r;
+      return OGE_OK;
+    }
+    case OGE_TSP: { /* tsp.py:201-258 */
+      if (action == e->start && e->head == e->start) { /* :203-211 */
+        *done = 1; *solved = 0; *reward = -(double)n; e->cost64 = -1.0; compute_mask(e); return OGE_OK;
+      }
+      if (action < 0 || action >= n || !e->mask[action]) return OGE_INVALID_ACTION;
+      int a = (int)action;
+      double r = 0.0 - e->adjw[e->head * n + a];
+      e->cost64 += e->adjw[e->head * n + a];
+      e->x[a * F + 0] = 1.f;
+      if (e->cfg.parenting >= 2 && a != e->start) { e->alive[a] = 0; e->n_alive--; }
+      e->head = a;
+      int any_untaken = 0;
+      for (int v = 0; v < n; v++) if (e->x[v * F + 0] == 0.f) any_untaken = 1;
+      if (!any_untaken && a == e->start) { *done = 1; *solved = 1; }
+      compute_mask(e);
+      if (!*done && mask_sum(e) == 0) { *done = 1; r -= (double)(n * 2); *solved = 0; }
+      *reward = r;
+      return OGE_OK;
+    }
+    case OGE_DENSEST_SUBGRAPH: { /* densest_subgraph.py:135-196 */
+      if (action < 0 || action >= n || !e->mask[action] || e->x[action * F + 0] == 1.0f) return OGE_INVALID_ACTION;
+      int a = (int)action;
+      *solved = 1;
+      if (a == n - 1) { *reward = 0.0; *done = 1; compute_mask(e); return OGE_OK; }
+      int64_t new_edges = 0;
+      for (int k = e->row_ptr[a]; k < e->row_ptr[a + 1]; k++) if (e->dtaken[e->col[k]]) new_edges++;
+      double r;
+      if (e->nodes_taken_cnt == 0) r = 0.0;
+      else r = ((double)(e->edge_taken_cnt + new_edges) / (double)(e->nodes_taken_cnt + 1)) - ((double)e->edge_taken_cnt / (double)e->nodes_taken_cnt);
+      e->edge_taken_cnt += new_edges;
+      e->dtaken[a] = 1; e->nodes_taken_cnt++;
+      e->x[a * F + 0] = 1.f;
+      e->cost64 = (double)e->edge_taken_cnt / (double)e->nodes_taken_cnt;
+      compute_mask(e);
+      if ((double)e->nodes_taken_cnt == e->n_choices) *done = 1;
+      *reward = r;
+      return OGE_OK;
+    }
+    case OGE_MAX_INDEPENDENT_SET: { /* max_independent_set.py:102-124 */
+      if (action < 0 || action >= n || !e->mask[action]) return OGE_INVALID_ACTION;
+      int a = (int)action;
+      float r = -e->x[a * F + 0];
+      e->cost32 -= r;
+      e->x[a * F + 1] = 1.f;
+      compute_mask(e);
+      if (mask_sum(e) == 0) { *done = 1; *solved = 1; }
+      *reward = (double)r;
+      return OGE_OK;
+    }
+  }
+  return OGE_INVALID_ACTION;
+}
+
+/* ------------------------------------------------------------------ readers */
+void oge_get_nodes(const oge_env *e, float *x) { memcpy(x, e->x, (size_t)e->n * e->F * sizeof(float)); }
+void oge_get_edges(const oge_env *e, float *ef) { memcpy(ef, e->ef, (size_t)e->E * e->Fe * sizeof(float)); }
+void oge_get_edge_links(const oge_env *e, int64_t *l) { memcpy(l, e->links, (size_t)2 * e->E * sizeof(int64_t)); }
+void oge_get_obs(const oge_env *e, float *obs) { /* utils.py:87-88 */
+  size_t p1 = (size_t)e->n * e->F, p2 = (size_t)e->E * e->Fe;
+  memcpy(obs, e->x, p1 * sizeof(float)); memcpy(obs + p1, e->ef, p2 * sizeof(float));
+  for (size_t i = 0; i < (size_t)2 * e->E; i++) obs[p1 + p2 + i] = (float)e->links[i];
+}
+void oge_get_mask(const oge_env *e, uint8_t *mask) { memcpy(mask, e->mask, e->A); }
+void oge_get_features64(const oge_env *e, double *sf) { memcpy(sf, e->sf64, (size_t)e->n * 5 * sizeof(double)); }
+double oge_solution_cost(const oge_env *e) {
+  int t = e->cfg.env_type;
+  return (t == OGE_STEINER_TREE || t == OGE_MAX_INDEPENDENT_SET) ? (double)e->cost32 : e->cost64;
+}
+double oge_heuristic_solution(const oge_env *e) { return e->heuristic; }
+int oge_head(const oge_env *e) { return e->head; }
+int oge_num_targets(const oge_env *e) { return e->n_targets; }
+void oge_get_terminals(const oge_env *e, int32_t *out) { for (int i = 0; i <= e->n_targets; i++) out[i] = e->terms[i]; }
+
+/* ------------------------------------------------------------------ policy + rollout */
+static uint64_t mix64(uint64_t z) { /* splitmix64 finaliser */
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+int64_t oge_policy_pick(const uint8_t *mask, int n, uint64_t policy_seed, uint64_t env_index, uint64_t t) {
+  uint32_t cnt = 0;
+  for (int i = 0; i < n; i++) cnt += mask[i] != 0;
+  if (!cnt) return -1;
+  uint64_t z = mix64(policy_seed + env_index * 0x9E3779B97F4A7C15ull + t * 0xD1B54A32D192ED03ull);
+  uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
+  for (int i = 0; i < n; i++) if (mask[i]) { if (!r) return i; r--; }
+  return -1;
+}
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+int64_t oge_rollout(const oge_cfg *cfg, int64_t first_seed, int64_t seed_stride, int32_t n_envs,
+                    int32_t n_steps, uint64_t policy_seed, int32_t n_threads,
+                    double *out_sum_reward, int64_t *out_episodes, double *out_reset_seconds) {
+  int64_t total = 0, episodes = 0; double sum_r = 0.0, reset_s = 0.0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total, episodes, sum_r, reset_s)
+  for (int i = 0; i < n_envs; i++) {
+    oge_env *e = oge_create(cfg);
+    int64_t k = 0; uint64_t t = 0;
+    double t0 = now_s();
+    oge_reset(e, (first_seed + i) & 0xffffffffll);
+    reset_s += now_s() - t0;
+    for (int s = 0; s < n_steps; s++) {
+      int64_t a = oge_policy_pick(e->mask, e->A, policy_seed, (uint64_t)i, t);
+      double r; int32_t d, sv;
+      if (a < 0 || oge_step(e, a, &r, &d, &sv) != OGE_OK) { d = 1; r = 0; }
+      t++; total++; sum_r += r;
+      if (d) {
+        episodes++; k++;
+        t0 = now_s();
+        oge_reset(e, (first_seed + i + k * seed_stride) & 0xffffffffll);
+        reset_s += now_s() - t0;
+      }
+    }
+    oge_destroy(e);
+  }
+  if (out_sum_reward) *out_sum_reward = sum_r;
+  if (out_episodes) *out_episodes = episodes;
+  if (out_reset_seconds) *out_reset_seconds = reset_s;
+  return total;
+}

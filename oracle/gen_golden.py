@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator (runs in the build container only).
+
+Imports the real reference from /root/reference through oracle/refshim.py, rolls every
+in-scope env with two deterministic policies and writes compact fixtures to
+tests/golden/<case>.npz.  A fixture is data only: inputs (env id, kwargs, seeds, actions) and
+the reference's outputs (obs, masks, rewards, done flags, info values).  No reference source
+is stored.  Re-run:  python oracle/gen_golden.py [--only NAME]
+"""
+import argparse
+import hashlib
+import json
+import os
+import platform
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# name -> (env_id, kwargs, seeds)
+CASES = {
+    # BASELINE config 1 (plumbing) and SURVEY section 10 rows
+    "sp_n10_m20_eval": ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, is_eval_env=True), list(range(16))),
+    "sp_n10_m20_unweighted": ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, weighted=False, is_eval_env=True), list(range(4))),
+    "sp_n5_m7": ("ShortestPath-v0", dict(n_nodes=5, n_edges=7), list(range(8))),
+    # BASELINE config 2 (headline)
+    "sp_n64_m192_eval": ("ShortestPath-v0", dict(n_nodes=64, n_edges=192, is_eval_env=True), [0, 1, 2, 3, 4, 5, 6, 7, 12345, 4294967295]),
+    "sp_n33_m70": ("ShortestPath-v0", dict(n_nodes=33, n_edges=70, is_eval_env=True), list(range(4))),
+    "lp_n10_m20_p0": ("LongestPath-v0", dict(n_nodes=10, n_edges=20, parenting=0, is_eval_env=True), list(range(6))),
+    "lp_n10_m20_p1": ("LongestPath-v0", dict(n_nodes=10, n_edges=20, parenting=1, is_eval_env=True), list(range(8))),
+    "lp_n10_m20_p2": ("LongestPath-v0", dict(n_nodes=10, n_edges=20, parenting=2, is_eval_env=True), list(range(8))),
+    "lp_n64_m192_p2": ("LongestPath-v0", dict(n_nodes=64, n_edges=192, parenting=2), list(range(4))),
+    "st_n10_m20_d3_eval": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=3, is_eval_env=True), list(range(8))),
+    "st_n10_m20_d1_eval": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=1, is_eval_env=True), list(range(6))),
+    "st_n10_m20_d9_eval": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=9, is_eval_env=True), list(range(6))),
+    "st_n5_m10_d4": ("SteinerTree-v0", dict(n_nodes=5, n_edges=10, n_dests=4), list(range(4))),
+    "st_n10_m20_d3_unweighted": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=3, weighted=False), list(range(3))),
+    # BASELINE config 4
+    "st_n256_m1024_d8": ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), [0, 1]),
+    "tsp_n8_m28_p1": ("TSP-v0", dict(n_nodes=8, n_edges=28, parenting=1), list(range(6))),
+    "tsp_n10_m20_p1": ("TSP-v0", dict(n_nodes=10, n_edges=20, parenting=1), list(range(8))),
+    "tsp_n10_m20_p2": ("TSP-v0", dict(n_nodes=10, n_edges=20, parenting=2), list(range(8))),
+    "tsp_n12_m30_p2_spatial": ("TSP-v0", dict(n_nodes=12, n_edges=30, parenting=2, spatial=True), list(range(4))),
+    "tsp_n12_m30_p1_unweighted": ("TSP-v0", dict(n_nodes=12, n_edges=30, parenting=1, weighted=False), list(range(3))),
+    # BASELINE config 3
+    "tsp_n128_complete_p1": ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), [0]),
+    "mis_n6_m8": ("MaxIndependentSet-v0", dict(n_nodes=6, n_edges=8), list(range(6))),
+    "mis_n5_m7_unweighted": ("MaxIndependentSet-v0", dict(n_nodes=5, n_edges=7, weighted=False), list(range(4))),
+    "mis_n64_m192": ("MaxIndependentSet-v0", dict(n_nodes=64, n_edges=192), list(range(4))),
+    "ds_n10_m20_p1": ("DensestSubgraph-v0", dict(n_nodes=10, n_edges=20, parenting=1), list(range(8))),
+    "ds_n10_m20_p0_eval": ("DensestSubgraph-v0", dict(n_nodes=10, n_edges=20, parenting=0, is_eval_env=True), list(range(8))),
+    "ds_n64_m192_p1": ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), list(range(4))),
+    # BASELINE config 5 (ragged sizes; the three env types at the extremes of n in [32,512], m=3n)
+    "sp_n32_m96": ("ShortestPath-v0", dict(n_nodes=32, n_edges=96), [0, 1]),
+    "sp_n512_m1536": ("ShortestPath-v0", dict(n_nodes=512, n_edges=1536), [0]),
+    "mis_n200_m600": ("MaxIndependentSet-v0", dict(n_nodes=200, n_edges=600), [0]),
+    "ds_n100_m300_p1": ("DensestSubgraph-v0", dict(n_nodes=100, n_edges=300, parenting=1), [0, 1]),
+}
+
+POLICIES = ("first", "rand")
+
+
+def sha64(a: np.ndarray) -> np.uint64:
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()[:8], dtype=np.uint64)[0]
+
+
+def pick(policy, mask, rng):
+    va = np.nonzero(mask)[0]
+    if len(va) == 0:
+        return -1
+    return int(va[0]) if policy == "first" else int(rng.choice(va))
+
+
+def terminals_of(env, env_id):
+    if env_id in ("ShortestPath-v0", "LongestPath-v0"):
+        return [int(env.src), int(env.dest)]
+    if env_id == "SteinerTree-v0":
+        return [int(env.src)] + [int(d) for d in env.dests]
+    if env_id == "TSP-v0":
+        return [0]
+    return []
+
+
+def roll(gym, env_id, kwargs, seed, policy, max_steps=100000):
+    env = gym.make(env_id, **kwargs)
+    obs, info = env.reset(seed=seed)
+    rec = dict(reset_obs=obs.copy(), reset_mask=info["mask"].copy(), terminals=terminals_of(env, env_id))
+    rng = np.random.default_rng(1000 + seed)
+    acts, rews, dones, masks, shas = [], [], [], [], []
+    mask = info["mask"]
+    final = dict(solved=-1, solution_cost=np.nan, heuristic_solution=np.nan)
+    for _ in range(max_steps):
+        a = pick(policy, mask, rng)
+        if a < 0:
+            break
+        obs, r, d, trunc, info = env.step(a)
+        assert trunc is False
+        acts.append(a); rews.append(float(r)); dones.append(bool(d)); shas.append(sha64(obs))
+        if "mask" in info:
+            mask = info["mask"]
+        masks.append(np.asarray(mask, dtype=bool).copy())
+        if d:
+            if "solved" in info:
+                final["solved"] = int(bool(info["solved"]))
+            final["solution_cost"] = float(info["solution_cost"])
+            final["heuristic_solution"] = float(info["heuristic_solution"])
+            break
+    rec.update(actions=acts, rewards=rews, dones=dones, masks=masks, obs_sha=shas, final_obs=obs.copy(), **final)
+    # reset(seed=None) continues the process-global streams (shortest_path.py:49-52)
+    obs2, info2 = env.reset()
+    rec["reset2_obs_sha"] = sha64(obs2)
+    rec["reset2_mask"] = info2["mask"].copy()
+    return rec
+
+
+def build_case(gym, name):
+    import networkx, scipy
+    env_id, kwargs, seeds = CASES[name]
+    out = {}
+    for policy in POLICIES:
+        recs = [roll(gym, env_id, kwargs, s, policy) for s in seeds]
+        S = len(recs)
+        T = max(len(r["actions"]) for r in recs)
+        A = len(recs[0]["reset_mask"])
+        L = len(recs[0]["reset_obs"])
+        K = len(recs[0]["terminals"])
+        P = policy + "_"
+        out[P + "length"] = np.array([len(r["actions"]) for r in recs], dtype=np.int32)
+        acts = np.full((S, T), -1, dtype=np.int32)
+        rews = np.zeros((S, T), dtype=np.float64)
+        dones = np.zeros((S, T), dtype=bool)
+        shas = np.zeros((S, T), dtype=np.uint64)
+        masks = np.zeros((S, T, (A + 7) // 8), dtype=np.uint8)
+        for i, r in enumerate(recs):
+            t = len(r["actions"])
+            acts[i, :t] = r["actions"]; rews[i, :t] = r["rewards"]; dones[i, :t] = r["dones"]; shas[i, :t] = r["obs_sha"]
+            if t:
+                masks[i, :t] = np.packbits(np.stack(r["masks"]), axis=1, bitorder="little")
+        out[P + "actions"], out[P + "rewards"], out[P + "dones"] = acts, rews, dones
+        out[P + "obs_sha"], out[P + "masks_packed"] = shas, masks
+        out[P + "final_obs"] = np.stack([r["final_obs"] for r in recs]).astype(np.float32)
+        out[P + "solved"] = np.array([r["solved"] for r in recs], dtype=np.int8)
+        out[P + "solution_cost"] = np.array([r["solution_cost"] for r in recs], dtype=np.float64)
+        out[P + "heuristic_solution"] = np.array([r["heuristic_solution"] for r in recs], dtype=np.float64)
+        out[P + "reset2_obs_sha"] = np.array([r["reset2_obs_sha"] for r in recs], dtype=np.uint64)
+        out[P + "reset2_mask"] = np.stack([r["reset2_mask"] for r in recs])
+        if policy == POLICIES[0]:
+            out["reset_obs"] = np.stack([r["reset_obs"] for r in recs]).astype(np.float32)
+            out["reset_mask"] = np.stack([r["reset_mask"] for r in recs]).astype(bool)
+            out["terminals"] = np.array([r["terminals"] for r in recs], dtype=np.int32).reshape(S, K)
+            assert out["reset_obs"].shape == (S, L)
+    meta = dict(case=name, env_id=env_id, kwargs=kwargs, seeds=[int(s) for s in seeds], policies=list(POLICIES),
+                rand_policy="numpy default_rng(1000+seed).choice(valid_actions)",
+                versions=dict(python=platform.python_version(), numpy=np.__version__,
+                              networkx=networkx.__version__, scipy=scipy.__version__),
+                source="reference teshnizi/GraphEnvs graph-envs 0.0.54 via oracle/refshim.py")
+    out["meta"] = np.array(json.dumps(meta))
+    out["seeds"] = np.array(seeds, dtype=np.int64)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    gym, _ = refshim.load_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for name in CASES:
+        if args.only and args.only != name:
+            continue
+        t0 = time.time()
+        data = build_case(gym, name)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB in {time.time() - t0:.1f}s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

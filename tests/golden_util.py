@@ -1,0 +1,89 @@
+"""Helpers shared by the parity tests: load tests/golden/*.npz and replay them on any env object
+that has the reference's reset(seed=)/step(a) shape."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    d["meta"] = json.loads(str(d["meta"]))
+    return d
+
+
+def sha64(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()[:8], dtype=np.uint64)[0]
+
+
+def unpack_mask(packed, A):
+    return np.unpackbits(packed, bitorder="little")[:A].astype(bool)
+
+
+def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True, feature_slice=None,
+                feature_ulps=0):
+    """Replay every seed/policy of a fixture on env = make_env(env_id, **kwargs).
+
+    feature_slice/feature_ulps: columns of x holding float64-derived structural features may be
+    compared with a tolerance in float32 ulps (0 = bit exact); every other float is compared exactly.
+    Returns a dict of counters."""
+    meta = case["meta"]
+    env_id, kwargs = meta["env_id"], meta["kwargs"]
+    n = kwargs["n_nodes"]
+    stats = dict(resets=0, steps=0, inexact_feature_values=0)
+
+    def obs_equal(got, want, what):
+        if feature_ulps == 0 or feature_slice is None:
+            assert got.shape == want.shape and np.array_equal(got, want), what
+            return
+        assert got.shape == want.shape, what
+        F = feature_slice[2]
+        gx, wx = got[: n * F].reshape(n, F), want[: n * F].reshape(n, F)
+        lo, hi = feature_slice[0], feature_slice[1]
+        assert np.array_equal(gx[:, :lo], wx[:, :lo]), what + " (flag columns)"
+        assert np.array_equal(got[n * F:], want[n * F:]), what + " (edge part)"
+        gi, wi = gx[:, lo:hi].view(np.int32).astype(np.int64), wx[:, lo:hi].view(np.int32).astype(np.int64)
+        assert np.abs(gi - wi).max() <= feature_ulps, what + " (structural features)"
+        stats["inexact_feature_values"] += int((gi != wi).sum())
+
+    for si, seed in enumerate(case["seeds"]):
+        for pol in policies:
+            env = make_env(env_id, **kwargs)
+            obs, info = env.reset(seed=int(seed))
+            stats["resets"] += 1
+            obs_equal(np.asarray(obs), case["reset_obs"][si], f"{meta['case']} seed {seed}: reset obs")
+            assert np.array_equal(np.asarray(info["mask"]), case["reset_mask"][si]), f"{meta['case']} seed {seed}: reset mask"
+            T = int(case[pol + "_length"][si])
+            A = case["reset_mask"].shape[1]
+            for t in range(T):
+                a = int(case[pol + "_actions"][si, t])
+                obs, r, d, trunc, info = env.step(a)
+                stats["steps"] += 1
+                tag = f"{meta['case']} seed {seed} policy {pol} t {t}"
+                assert float(r) == float(case[pol + "_rewards"][si, t]), tag + f": reward {r} != {case[pol + '_rewards'][si, t]}"
+                assert bool(d) == bool(case[pol + "_dones"][si, t]), tag + ": done"
+                assert trunc is False or not bool(trunc)
+                want_mask = unpack_mask(case[pol + "_masks_packed"][si, t], A)
+                assert np.array_equal(np.asarray(info["mask"]), want_mask), tag + ": mask"
+                if feature_ulps == 0:
+                    assert sha64(np.asarray(obs)) == case[pol + "_obs_sha"][si, t], tag + ": obs hash"
+            if T:
+                obs_equal(np.asarray(obs), case[pol + "_final_obs"][si], f"{meta['case']} seed {seed} {pol}: final obs")
+                if bool(case[pol + "_dones"][si, T - 1]):
+                    want_solved = int(case[pol + "_solved"][si])
+                    got_solved = int(bool(info["solved"])) if "solved" in info else -1
+                    assert got_solved == want_solved, f"{meta['case']} seed {seed} {pol}: solved"
+                    assert float(info["solution_cost"]) == float(case[pol + "_solution_cost"][si]), f"{meta['case']} seed {seed} {pol}: solution_cost"
+                    h = float(info["heuristic_solution"])
+                    if check_heuristic and not np.isnan(h):
+                        assert h == float(case[pol + "_heuristic_solution"][si]), f"{meta['case']} seed {seed} {pol}: heuristic {h}"
+    return stats

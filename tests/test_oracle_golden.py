@@ -1,0 +1,100 @@
+"""CPU: the C oracle (oracle/ge_oracle.c) against the golden vectors captured from the real
+reference (oracle/gen_golden.py), plus the known answers of SURVEY.md section 10 and the two
+MT19937 streams against CPython / numpy themselves."""
+import random
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_oracle_matches_reference_golden(name):
+    case = gu.load_case(name)
+    stats = gu.replay_case(case, lambda env_id, **kw: oracle.OracleEnv(env_id, **kw))
+    assert stats["resets"] > 0
+
+
+@pytest.mark.parametrize("name", ["sp_n10_m20_eval", "st_n10_m20_d3_eval", "ds_n10_m20_p1", "mis_n6_m8", "tsp_n10_m20_p2"])
+def test_oracle_continues_streams_on_unseeded_reset(name):
+    """reset(seed=None) continues the MT19937 streams (shortest_path.py:49-52)."""
+    case = gu.load_case(name)
+    meta = case["meta"]
+    for si, seed in enumerate(case["seeds"]):
+        env = oracle.OracleEnv(meta["env_id"], **meta["kwargs"])
+        env.reset(seed=int(seed))
+        T = int(case["first_length"][si])
+        for t in range(T):
+            env.step(int(case["first_actions"][si, t]))
+        obs2, info2 = env.reset()
+        assert gu.sha64(obs2) == case["first_reset2_obs_sha"][si]
+        assert np.array_equal(info2["mask"], case["first_reset2_mask"][si])
+
+
+def test_survey_known_answers():
+    """SURVEY.md section 10, seed 0, lowest-valid-index policy."""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    e = oracle.OracleEnv("ShortestPath-v0", n_nodes=10, n_edges=20, is_eval_env=True)
+    obs, info = e.reset(seed=0)
+    assert len(obs) == 190 and sha(obs) == "c2040d7d83b56476" and sha(e.edge_links()) == "560e8ee18327c253"
+    assert list(e.terminals()) == [2, 4]
+    assert "".join(str(int(b)) for b in info["mask"]) == "0001100011"
+    rs = []
+    for a in (3, 1, 4):
+        obs, r, d, _, info = e.step(a)
+        rs.append(r)
+    assert rs == [-0.8, -0.3, -0.7] and d and info["solved"] is True
+    assert info["heuristic_solution"] == 0.3 and info["solution_cost"] == 1.8 and sha(obs) == "39737d0aab663239"
+    assert "".join(str(int(b)) for b in info["mask"]) == "1000001010"
+
+    e = oracle.OracleEnv("SteinerTree-v0", n_nodes=10, n_edges=20, n_dests=9, is_eval_env=True)
+    obs, info = e.reset(seed=0)
+    assert sha(obs) == "85f8267b9b5dd68f" and list(e.terminals()) == [2, 4, 6, 3, 9, 1, 0, 8, 5, 7]
+    for a in (8, 9, 10, 11, 13, 14, 6, 16, 21):
+        obs, r, d, _, info = e.step(a)
+    assert d and info["heuristic_solution"] == 3.2 and abs(info["solution_cost"] - 4.3) < 1e-6 and not info["mask"].any()
+
+    e = oracle.OracleEnv("TSP-v0", n_nodes=10, n_edges=20, parenting=2)
+    obs, info = e.reset(seed=0)
+    assert len(obs) == 210 and sha(obs) == "33286effa4e58caf"
+    assert "".join(str(int(b)) for b in info["mask"]) == "0000100011"
+    for a in (4, 1, 3, 9, 2, 8, 7, 5, 6):
+        obs, r, d, _, info = e.step(a)
+    assert d and info["solved"] is False and abs(r + 20.9) < 1e-12 and abs(info["solution_cost"] - 5.3) < 1e-12
+
+    e = oracle.OracleEnv("DensestSubgraph-v0", n_nodes=10, n_edges=20, parenting=1)
+    obs, info = e.reset(seed=0)
+    assert len(obs) == 180 and sha(obs) == "c93b059b99574f1a" and sha(e.edge_links()) == "f328476caf411c60"
+    rs = [e.step(a)[1] for a in (0, 4, 1)]
+    assert rs[0] == 0 and rs[1] == 0.5 and abs(rs[2] - 1 / 6) < 1e-15
+    assert "".join(str(int(b)) for b in e.mask()) == "0011011110"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 7, 12345, 2**32 - 1])
+def test_mt19937_streams_match_cpython_and_numpy(seed):
+    """python random.seed(int) = init_by_array([s]); np.random.seed(int) = init_genrand(s)."""
+    py = oracle.mt_stream("py", seed, 1500)
+    random.seed(seed)
+    assert [random.getrandbits(32) for _ in range(1500)] == py.tolist()
+    npy = oracle.mt_stream("np", seed, 1500)
+    rs = np.random.RandomState(seed)
+    want = rs.randint(0, 2**32, size=1500, dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(npy, want)
+
+
+def test_policy_pick_is_uniform_and_deterministic():
+    mask = np.zeros(64, dtype=np.uint8)
+    mask[[3, 17, 40, 63]] = 1
+    picks = [oracle.policy_pick(mask, 42, 5, t) for t in range(4000)]
+    assert picks == [oracle.policy_pick(mask, 42, 5, t) for t in range(4000)]
+    counts = np.bincount(picks, minlength=64)
+    assert set(np.nonzero(counts)[0]) == {3, 17, 40, 63} and counts[counts > 0].min() > 850
+    assert oracle.policy_pick(np.zeros(8, dtype=np.uint8), 1, 2, 3) == -1
+
+
+def test_rollout_counts_transitions():
+    out = oracle.rollout("ShortestPath-v0", n_envs=8, n_steps=50, n_nodes=10, n_edges=20, n_threads=2)
+    assert out["transitions"] == 400 and out["episodes"] > 8
