@@ -1,0 +1,144 @@
+"""ctypes binding of libgraphenvs_hip.so (C ABI: include/graphenvs.h).
+
+The HIP library is the product: if it is missing or does not load, importing an engine raises.
+There is no CPU fallback.  (tests/emu builds the same sources for a CPU sanitizer run and passes
+that handle explicitly through the private ``_library`` argument of VectorGraphEnv.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libgraphenvs_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+GE_OK = 0
+ENV_TYPES = {
+    "ShortestPath-v0": 0,
+    "LongestPath-v0": 1,
+    "SteinerTree-v0": 2,
+    "TSP-v0": 3,
+    "DensestSubgraph-v0": 4,
+    "MaxIndependentSet-v0": 5,
+}
+
+
+class GeConfig(C.Structure):
+    _fields_ = [
+        ("env_type", C.c_int32), ("num_envs", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
+        ("weighted", C.c_int32), ("parenting", C.c_int32), ("n_dests", C.c_int32), ("spatial", C.c_int32),
+        ("is_eval_env", C.c_int32), ("autoreset", C.c_int32), ("n_choices", C.c_double),
+        ("env_index_base", C.c_int64), ("seed_stride", C.c_int64),
+    ]
+
+
+class GeLayout(C.Structure):
+    _fields_ = [
+        ("F", C.c_int32), ("Fe", C.c_int32), ("A", C.c_int32), ("W", C.c_int32), ("E", C.c_int32),
+        ("total_nodes", C.c_int64), ("total_edges", C.c_int64), ("obs_len", C.c_int64),
+        ("reset_lds_bytes", C.c_int64),
+    ]
+
+
+BUFFER_FIELDS = [
+    "x", "edge_index", "edge_attr", "row_ptr", "colw", "adj_bits", "rev_edge", "head", "terminals",
+    "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic",
+    "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
+    "final_len", "reset_list", "reset_count",
+]
+
+
+class GeBuffers(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in BUFFER_FIELDS]
+
+
+# every symbol include/graphenvs.h declares
+SYMBOLS = [
+    "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_reset", "ge_step", "ge_step_only",
+    "ge_reset_pending", "ge_inject_state", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
+    "ge_timed_rollout", "ge_last_error",
+]
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [
+        os.path.join(ROOT, "include", "graphenvs.h")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile the HIP library for gfx950 (works without a GPU)."""
+    srcs = sources()
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # float64 feature/baseline arithmetic must match CPython/numpy bit for bit: no FMA contraction
+           "-ffp-contract=off", "-I" + CSRC, os.path.join(CSRC, "ge_api.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL,
+                          stderr=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def bind(lib):
+    """Attach argtypes/restypes for every entry point of include/graphenvs.h."""
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    lib.ge_abi_version.restype = C.c_int
+    lib.ge_abi_version.argtypes = []
+    lib.ge_get_layout.restype = C.c_int
+    lib.ge_get_layout.argtypes = [C.POINTER(GeConfig), C.POINTER(GeLayout)]
+    lib.ge_create.restype = C.c_int
+    lib.ge_create.argtypes = [C.POINTER(GeConfig), C.POINTER(GeBuffers), C.POINTER(vp)]
+    lib.ge_destroy.restype = C.c_int
+    lib.ge_destroy.argtypes = [vp]
+    lib.ge_reset.restype = C.c_int
+    lib.ge_reset.argtypes = [vp, vp, vp]
+    for name in ("ge_step", "ge_step_only"):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [vp, vp, vp]
+    lib.ge_reset_pending.restype = C.c_int
+    lib.ge_reset_pending.argtypes = [vp, vp]
+    lib.ge_inject_state.restype = C.c_int
+    lib.ge_inject_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.ge_vectorize.restype = C.c_int
+    lib.ge_vectorize.argtypes = [vp, vp, vp]
+    lib.ge_sample_actions.restype = C.c_int
+    lib.ge_sample_actions.argtypes = [vp, u64, vp, vp]
+    lib.ge_random_rollout.restype = C.c_int
+    lib.ge_random_rollout.argtypes = [vp, u64, i32, vp, vp]
+    lib.ge_timed_rollout.restype = C.c_int
+    lib.ge_timed_rollout.argtypes = [vp, u64, i32, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]
+    lib.ge_last_error.restype = C.c_char_p
+    lib.ge_last_error.argtypes = []
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise loudly if it is not there (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"graphenvs_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            if not hasattr(lib, s):
+                raise RuntimeError(f"graphenvs_amd: {LIB_PATH} does not export {s}")
+        bind(lib)
+        if lib.ge_abi_version() != 1:
+            raise RuntimeError("graphenvs_amd: ABI version mismatch between the python host and the HIP library")
+        _lib = lib
+    return _lib
+
+
+def check(lib, rc, what):
+    if rc != GE_OK:
+        msg = lib.ge_last_error()
+        raise RuntimeError(f"graphenvs_amd: {what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,231 @@
+// C ABI of libgraphenvs_hip.so (include/graphenvs.h): config validation, buffer binding and
+// kernel launches.  No device allocation, no synchronisation (except ge_timed_rollout).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "ge_params.h"
+#include "ge_platform.h"
+#include "ge_reset.h"
+#include "ge_step.h"
+
+struct ge_engine {
+  GeParams P;
+  ge_config cfg;
+  int phase;          // which reset counter the next step kernel appends to
+  int reset_grid;     // workgroups of the queue-mode reset launch
+  int lds_bytes;
+  hipEvent_t ev[4];
+  bool have_events;
+};
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+extern "C" const char *ge_last_error(void) { return g_err; }
+extern "C" int ge_abi_version(void) { return GE_ABI_VERSION; }
+
+static const int kMaxLds = 160 * 1024;
+
+static int derive(const ge_config *cfg, GeParams &P) {
+  if (!cfg) return fail(GE_E_BADARG, "null config");
+  memset(&P, 0, sizeof(P));
+  const int t = cfg->env_type, n = cfg->n_nodes, m = cfg->n_edges;
+  if (t < GE_SHORTEST_PATH || t > GE_MAX_INDEPENDENT_SET) return fail(GE_E_BADARG, "unknown env_type");
+  if (cfg->num_envs < 1) return fail(GE_E_BADARG, "num_envs must be >= 1");
+  if (n < 3 || n > 4095) return fail(GE_E_BADARG, "n_nodes must be in [3, 4095]");
+  const int ng = (t == GE_DENSEST_SUBGRAPH) ? n - 1 : n;  // densest_subgraph.py:59
+  const double max_edges = (double)ng * (ng - 1) / 2.0;
+  if (m < ng - 1) return fail(GE_E_BADARG, "n_edges < nodes-1: no connected graph exists (the reference would loop forever)");
+  if (m > max_edges) return fail(GE_E_BADARG, "n_edges exceeds the complete graph");
+  // constructor asserts of the reference
+  if (t == GE_SHORTEST_PATH && cfg->parenting != -1) return fail(GE_E_BADARG, "Parenting is not available for shortest path (shortest_path.py:26)");
+  if (t == GE_STEINER_TREE && cfg->parenting != -1) return fail(GE_E_BADARG, "Parenting not available for this environment (steiner_tree.py:29)");
+  if (t == GE_LONGEST_PATH && (cfg->parenting < 0 || cfg->parenting > 3)) return fail(GE_E_BADARG, "parenting must be in [0,1,2,3] (longest_path.py:29)");
+  if (t == GE_TSP && cfg->parenting != 1 && cfg->parenting != 2) return fail(GE_E_BADARG, "Parenting must be either 1 or 2 (tsp.py:25)");
+  if (t == GE_DENSEST_SUBGRAPH && cfg->parenting != 0 && cfg->parenting != 1) return fail(GE_E_BADARG, "Parenting must be 0 or 1 (densest_subgraph.py:28)");
+  if (t == GE_DENSEST_SUBGRAPH && cfg->weighted) return fail(GE_E_BADARG, "Weighted graphs not supported for this env (densest_subgraph.py:29)");
+  if (t == GE_TSP && cfg->spatial && !cfg->weighted) return fail(GE_E_BADARG, "Spatial TSP must be weighted (tsp.py:27)");
+  if (t == GE_STEINER_TREE && (cfg->n_dests < 1 || cfg->n_dests > n - 1)) return fail(GE_E_BADARG, "n_dests must be in [1, n_nodes-1]");
+  // not built yet
+  if (t == GE_TSP && cfg->spatial) return fail(GE_E_UNSUPPORTED, "spatial TSP is not built yet");
+  if (t == GE_LONGEST_PATH && cfg->parenting >= 2) return fail(GE_E_UNSUPPORTED, "LongestPath parenting >= 2 is not built yet");
+  if (t == GE_TSP && cfg->parenting == 2) return fail(GE_E_UNSUPPORTED, "TSP parenting 2 is not built yet");
+
+  P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
+  P.nflag = (t == GE_TSP) ? 4 : (t == GE_DENSEST_SUBGRAPH ? 1 : 2);  // utils.py:32-73
+  P.F = P.nflag + 5;
+  P.Fe = (t == GE_STEINER_TREE) ? 2 : 1;
+  P.A = (t == GE_STEINER_TREE) ? P.E : n;  // steiner_tree.py:117
+  P.AW = (P.A + 63) / 64;
+  P.T = (t == GE_STEINER_TREE) ? (cfg->n_dests + 1 > 2 ? cfg->n_dests + 1 : 2) : 2;
+  P.weighted = cfg->weighted ? 1 : 0; P.parenting = cfg->parenting; P.n_dests = cfg->n_dests;
+  P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset ? 1 : 0;
+  P.complete = (m >= max_edges) ? 1 : 0;
+  P.n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;  // densest_subgraph.py:38-39
+  P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
+  if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
+  if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
+  ge_make_lds(P);
+  if (P.lds.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
+  return GE_OK;
+}
+
+extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
+  GeParams P;
+  int rc = derive(cfg, P);
+  if (rc != GE_OK) return rc;
+  if (!out) return fail(GE_E_BADARG, "null layout");
+  out->F = P.F; out->Fe = P.Fe; out->A = P.A; out->W = P.W; out->E = P.E;
+  out->total_nodes = (int64_t)P.B * P.n; out->total_edges = (int64_t)P.B * P.E;
+  out->obs_len = (int64_t)P.n * P.F + (int64_t)P.E * P.Fe + 2 * (int64_t)P.E;
+  out->reset_lds_bytes = P.lds.total;
+  return GE_OK;
+}
+
+extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out) {
+  if (!bufs || !out) return fail(GE_E_BADARG, "null argument");
+  GeParams P;
+  int rc = derive(cfg, P);
+  if (rc != GE_OK) return rc;
+  const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->adj_bits, bufs->head,
+                        bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->cost, bufs->counters, bufs->seed,
+                        bufs->episode, bufs->tstep, bufs->status, bufs->heuristic, bufs->mask, bufs->mask_bits, bufs->reward,
+                        bufs->terminated, bufs->invalid, bufs->solved, bufs->final_cost, bufs->final_heur, bufs->final_len,
+                        bufs->reset_list, bufs->reset_count};
+  for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
+  if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
+  P.buf = *bufs;
+  ge_engine *e = new (std::nothrow) ge_engine();
+  if (!e) return fail(GE_E_BADARG, "out of host memory");
+  e->P = P; e->cfg = *cfg; e->phase = 0; e->lds_bytes = P.lds.total; e->have_events = false;
+  int per_cu = kMaxLds / (P.lds.total > 0 ? P.lds.total : 1);
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) per_cu = 1;
+  e->reset_grid = 256 * per_cu;
+  if (e->reset_grid > P.B) e->reset_grid = P.B;
+  if (P.lds.total > 64 * 1024) {
+    hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset, P.lds.total);
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
+  }
+  *out = e;
+  return GE_OK;
+}
+
+extern "C" int ge_destroy(ge_engine *e) {
+  if (!e) return GE_OK;
+  if (e->have_events) for (int k = 0; k < 4; k++) hipEventDestroy(e->ev[k]);
+  delete e;
+  return GE_OK;
+}
+
+static int check_launch(const char *what) {
+  hipError_t hr = hipGetLastError();
+  if (hr != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(hr)); return GE_E_LAUNCH; }
+  return GE_OK;
+}
+
+static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, int slot, const GeInject &inj, void *stream) {
+  int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
+  GE_LAUNCH(ge_k_reset, grid, GE_WAVE, e->lds_bytes, stream, e->P, seeds, mode, slot, inj);
+  return check_launch("reset kernel");
+}
+
+extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
+  if (!e || !seeds) return fail(GE_E_BADARG, "null argument");
+  if (hipMemsetAsync(e->P.buf.reset_count, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "memset failed");
+  e->phase = 0;
+  GeInject none = {nullptr, nullptr, nullptr, nullptr};
+  return launch_reset(e, seeds, GE_RESET_ALL, 0, none, stream);
+}
+
+extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
+                               const int32_t *terminals, void *stream) {
+  if (!e || !links || !wcode || !x) return fail(GE_E_BADARG, "null argument");
+  const int t = e->P.env_type;
+  if ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) && !terminals) return fail(GE_E_BADARG, "terminals required");
+  if (hipMemsetAsync(e->P.buf.reset_count, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "memset failed");
+  e->phase = 0;
+  GeInject inj = {links, wcode, x, terminals};
+  return launch_reset(e, nullptr, GE_RESET_INJECT, 0, inj, stream);
+}
+
+static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P.W * 8 + GE_STEP_BLOCK; }
+
+extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {
+  if (!e || !actions) return fail(GE_E_BADARG, "null argument");
+  int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  GE_LAUNCH(ge_k_step, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, e->phase);
+  return check_launch("step kernel");
+}
+
+extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
+  if (!e) return fail(GE_E_BADARG, "null argument");
+  int rc = GE_OK;
+  if (e->P.autoreset) {
+    GeInject none = {nullptr, nullptr, nullptr, nullptr};
+    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, e->phase, none, stream);
+  }
+  e->phase ^= 1;
+  return rc;
+}
+
+extern "C" int ge_step(ge_engine *e, const int64_t *actions, void *stream) {
+  int rc = ge_step_only(e, actions, stream);
+  if (rc != GE_OK) return rc;
+  return ge_reset_pending(e, stream);
+}
+
+extern "C" int ge_vectorize(ge_engine *e, float *out, void *stream) {
+  if (!e || !out) return fail(GE_E_BADARG, "null argument");
+  int64_t L = (int64_t)e->P.n * e->P.F + (int64_t)e->P.E * e->P.Fe + 2 * (int64_t)e->P.E;
+  int64_t total = (int64_t)e->P.B * L;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  GE_LAUNCH(ge_k_vectorize, (int)blocks, 256, 0, stream, e->P, out);
+  return check_launch("vectorize kernel");
+}
+
+extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream) {
+  if (!e || !actions) return fail(GE_E_BADARG, "null argument");
+  int grid = (e->P.B + 255) / 256;
+  GE_LAUNCH(ge_k_sample, grid, 256, 0, stream, e->P, policy_seed, actions);
+  return check_launch("sample kernel");
+}
+
+extern "C" int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *scratch, void *stream) {
+  if (!e || !scratch) return fail(GE_E_BADARG, "null argument");
+  for (int s = 0; s < n_steps; s++) {
+    int rc = ge_sample_actions(e, policy_seed, scratch, stream);
+    if (rc == GE_OK) rc = ge_step(e, scratch, stream);
+    if (rc != GE_OK) return rc;
+  }
+  return GE_OK;
+}
+
+extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *scratch, void *stream,
+                                double *step_ms, double *reset_ms, double *policy_ms) {
+  if (!e || !scratch) return fail(GE_E_BADARG, "null argument");
+  if (!e->have_events) { for (int k = 0; k < 4; k++) if (hipEventCreate(&e->ev[k]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventCreate failed"); e->have_events = true; }
+  double ts = 0, tr = 0, tp = 0;
+  hipStream_t st = (hipStream_t)stream;
+  for (int s = 0; s < n_steps; s++) {
+    hipEventRecord(e->ev[0], st);
+    int rc = ge_sample_actions(e, policy_seed, scratch, stream);
+    hipEventRecord(e->ev[1], st);
+    if (rc == GE_OK) rc = ge_step_only(e, scratch, stream);
+    hipEventRecord(e->ev[2], st);
+    if (rc == GE_OK) rc = ge_reset_pending(e, stream);
+    hipEventRecord(e->ev[3], st);
+    if (rc != GE_OK) return rc;
+    if (hipEventSynchronize(e->ev[3]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventSynchronize failed");
+    float a = 0, b = 0, c = 0;
+    hipEventElapsedTime(&a, e->ev[0], e->ev[1]); hipEventElapsedTime(&b, e->ev[1], e->ev[2]); hipEventElapsedTime(&c, e->ev[2], e->ev[3]);
+    tp += a; ts += b; tr += c;
+  }
+  if (step_ms) *step_ms = ts;
+  if (reset_ms) *reset_ms = tr;
+  if (policy_ms) *policy_ms = tp;
+  return GE_OK;
+}

@@ -1,0 +1,59 @@
+// Engine parameters passed by value to every kernel, and the LDS carve of the reset kernel.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/graphenvs.h"
+
+#define GE_WAVE 64
+#define GE_MT_N 624
+#define GE_MT_M 397
+#define GE_STEP_BLOCK 256
+
+// byte offsets into the dynamic LDS of one reset workgroup (one env resident per workgroup)
+struct GeLds {
+  int mt;       // u32[624]  MT19937 state (python stream, then numpy stream)
+  int abits;    // u64[n*W]  adjacency bit rows
+  int elist;    // u32[m]    accepted edges in insertion order (u | v << 16); later G.edges order map
+  int fill;     // i32[n]    per-row fill counters / degrees
+  int rowptr;   // i32[n+1]
+  int colw;     // u16[E]    (col << 4) | weight code, insertion order
+  int scw;      // u16[E]    same, rows sorted by column (scipy canonical CSR)
+  int tmp;      // u32[E]    (edge id << 16 | col) scatter buffer
+  int dist;     // i32[n]
+  int perm;     // i32[n]
+  int f64a;     // f64[9][n] sigma, delta, coeff, bc, prx, prn, sinv, diff, clos
+  int bits;     // u64[4][W] frontier / visited / next / scratch
+  int misc;     // i32[16]
+  int total;
+};
+
+struct GeParams {
+  int32_t env_type, B, n, m, E, W, F, Fe, A, AW, T, ng, nflag;
+  int32_t weighted, parenting, n_dests, is_eval, autoreset, complete;
+  double n_choices;
+  int64_t env_index_base, seed_stride;
+  ge_buffers buf;
+  GeLds lds;
+};
+
+static inline int ge_align16(int v) { return (v + 15) & ~15; }
+
+static inline void ge_make_lds(GeParams &P) {
+  GeLds &L = P.lds;
+  int o = 0;
+  auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
+  L.mt = take(GE_MT_N * 4);
+  L.abits = take(P.n * P.W * 8);
+  L.elist = take((P.m > 0 ? P.m : 1) * 4);
+  L.fill = take(P.n * 4);
+  L.rowptr = take((P.n + 1) * 4);
+  L.colw = take((P.E > 0 ? P.E : 1) * 2);
+  L.scw = take((P.E > 0 ? P.E : 1) * 2);
+  L.tmp = take(P.complete ? 16 : (P.E > 0 ? P.E : 1) * 4);
+  L.dist = take(P.n * 4);
+  L.perm = take(P.n * 4);
+  L.f64a = take(9 * P.n * 8);
+  L.bits = take(4 * P.W * 8);
+  L.misc = take(16 * 4);
+  L.total = o;
+}

@@ -1,0 +1,42 @@
+// Thin names for the gfx950 wave64 primitives the kernels use.  The only alternative
+// definition of these names is the CPU sanitizer harness in tests/emu/hip_emu.h (-DGE_EMU),
+// which exists because GPU sanitizers are not available; the shipped library is always built
+// from the HIP definitions below.
+#pragma once
+#ifdef GE_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GE_DEV static __device__ __forceinline__
+#define GE_DEVFN __device__
+#define GE_KERNEL __global__ void
+#define GE_HOSTDEV __host__ __device__ inline
+
+GE_DEV int ge_tid() { return (int)threadIdx.x; }
+GE_DEV int ge_bid() { return (int)blockIdx.x; }
+GE_DEV int ge_bdim() { return (int)blockDim.x; }
+GE_DEV int ge_gdim() { return (int)gridDim.x; }
+GE_DEV unsigned char *ge_dyn_smem() {
+  extern __shared__ __align__(16) unsigned char ge_smem_raw[];
+  return ge_smem_raw;
+}
+GE_DEV void ge_sync() { __syncthreads(); }
+GE_DEV uint64_t ge_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+GE_DEV int ge_shfl_i32(int v, int src) { return __shfl(v, src, 64); }
+GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+GE_DEV uint64_t ge_shfl_u64(uint64_t v, int src) {
+  int lo = __shfl((int)(uint32_t)v, src, 64), hi = __shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+GE_DEV double ge_shfl_f64(double v, int src) { return __longlong_as_double((long long)ge_shfl_u64((uint64_t)__double_as_longlong(v), src)); }
+GE_DEV int ge_popc64(uint64_t v) { return __popcll(v); }
+GE_DEV int ge_ctz64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : 64; }
+GE_DEV int ge_clz32(uint32_t v) { return v ? (int)__builtin_clz(v) : 32; }
+
+#define GE_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), __VA_ARGS__)
+#define GE_SET_MAX_DYN_LDS(kernel, bytes) \
+  hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+#endif

@@ -1,0 +1,648 @@
+// Reset kernel: one wave64 workgroup regenerates one env slot entirely on the device, with the
+// slot's graph resident in LDS.  Replaces, per slot, the body of reset() in the six reference envs
+// (shortest_path.py:47-98, longest_path.py:53-118, steiner_tree.py:50-113, tsp.py:50-164,
+// densest_subgraph.py:52-98, max_independent_set.py:41-89) including the third-party arithmetic
+// they call: CPython random / numpy legacy MT19937 streams, networkx gnm_random_graph,
+// is_connected, the five structural features of feature_extraction.py:6-37, Dijkstra / MST totals.
+#pragma once
+#include "ge_params.h"
+#include "ge_platform.h"
+
+// weight code k -> k/10.0 (codes 3..9 = randint(3,10)/10.0, 10 = 1.0 for unweighted graphs)
+GE_DEV double ge_wlut(int code) {
+  switch (code) {
+    case 3: return 0.3; case 4: return 0.4; case 5: return 0.5; case 6: return 0.6;
+    case 7: return 0.7; case 8: return 0.8; case 9: return 0.9; default: return 1.0;
+  }
+}
+
+GE_DEV uint32_t ge_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+// regenerate all 624 words, 64 lanes wide (reads of a chunk complete before its writes)
+GE_DEV void ge_mt_twist(uint32_t *mt, int lane) {
+  for (int i0 = 0; i0 < GE_MT_N; i0 += GE_WAVE) {
+    int i = i0 + lane;
+    bool ok = i < GE_MT_N;
+    uint32_t a = 0, b = 0, c = 0;
+    if (ok) {
+      int i1 = i + 1; if (i1 == GE_MT_N) i1 = 0;
+      int im = i + GE_MT_M; if (im >= GE_MT_N) im -= GE_MT_N;
+      a = mt[i]; b = mt[i1]; c = mt[im];
+    }
+    ge_sync();
+    if (ok) {
+      uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+      mt[i] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    ge_sync();
+  }
+}
+
+// random.seed(int) for 0 <= s < 2^32: init_by_array([s]) ([py] _randommodule.c). One lane.
+GE_DEV void ge_mt_seed_python(uint32_t *mt, uint32_t seed) {
+  uint32_t b = 19650218u, prev = b;
+  mt[0] = b;
+  for (int i = 1; i < GE_MT_N; i++) {
+    b = 1812433253u * (b ^ (b >> 30)) + (uint32_t)i;            // init_genrand(19650218)[i]
+    prev = (b ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;      // + key[0] + j, j == 0
+    mt[i] = prev;
+  }
+  mt[0] = prev;  // i wrapped: mt[0] = mt[N-1]
+  prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;    // 624th iteration at i = 1
+  mt[1] = prev;
+  for (int i = 2; i < GE_MT_N; i++) {
+    prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+    mt[i] = prev;
+  }
+  mt[0] = prev;
+  mt[1] = (mt[1] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+  mt[0] = 0x80000000u;
+}
+
+// np.random.seed(int): init_genrand(s) ([np] mt19937.c). One lane.
+GE_DEV void ge_mt_seed_numpy(uint32_t *mt, uint32_t seed) {
+  uint32_t prev = seed;
+  mt[0] = prev;
+  for (int i = 1; i < GE_MT_N; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; mt[i] = prev; }
+}
+
+GE_DEV int ge_wave_incl_scan(int x, int lane) {
+  for (int off = 1; off < GE_WAVE; off <<= 1) {
+    int t = ge_shfl_i32(x, lane >= off ? lane - off : 0);
+    if (lane >= off) x += t;
+  }
+  return x;
+}
+
+GE_DEV uint32_t ge_mask_below(uint32_t v) {  // smallest 2^k - 1 >= v
+  v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+  return v;
+}
+
+struct GeRctx {
+  uint32_t *mt; uint64_t *abits; uint32_t *elist; int *fill; int *rowptr; uint16_t *colw; uint16_t *scw;
+  uint32_t *tmp; int *dist; int *perm;
+  double *sigma, *delta, *coeff, *bc, *prx, *prn, *sinv, *diff, *clos;
+  uint64_t *bits; int *misc;
+};
+
+GE_DEV GeRctx ge_carve(const GeParams &P) {
+  unsigned char *s = ge_dyn_smem();
+  const GeLds &L = P.lds;
+  GeRctx c;
+  c.mt = (uint32_t *)(s + L.mt); c.abits = (uint64_t *)(s + L.abits); c.elist = (uint32_t *)(s + L.elist);
+  c.fill = (int *)(s + L.fill); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
+  c.scw = (uint16_t *)(s + L.scw); c.tmp = (uint32_t *)(s + L.tmp); c.dist = (int *)(s + L.dist);
+  c.perm = (int *)(s + L.perm);
+  double *f = (double *)(s + L.f64a);
+  c.sigma = f; c.delta = f + P.n; c.coeff = f + 2 * P.n; c.bc = f + 3 * P.n; c.prx = f + 4 * P.n;
+  c.prn = f + 5 * P.n; c.sinv = f + 6 * P.n; c.diff = f + 7 * P.n; c.clos = f + 8 * P.n;
+  c.bits = (uint64_t *)(s + L.bits); c.misc = (int *)(s + L.misc);
+  return c;
+}
+
+// [nx] is_connected over nodes [0,ng) minus `skip`, as a level-synchronous BFS on the bit rows
+GE_DEV bool ge_connected(const GeRctx &c, int ng, int W, int skip, int lane) {
+  uint64_t *fr = c.bits, *vis = c.bits + W, *nx = c.bits + 2 * W;
+  int start = (skip == 0) ? 1 : 0;
+  if (lane < W) {
+    uint64_t s = ((start >> 6) == lane) ? (1ull << (start & 63)) : 0ull;
+    uint64_t v = s;
+    if (skip >= 0 && (skip >> 6) == lane) v |= 1ull << (skip & 63);
+    fr[lane] = s; vis[lane] = v;
+  }
+  ge_sync();
+  for (;;) {
+    uint64_t any = 0;
+    for (int k = 0; k < W; k++) {
+      int v = k * GE_WAVE + lane;
+      bool hit = false;
+      if (v < ng && !((vis[k] >> lane) & 1ull)) {
+        for (int w = 0; w < W; w++) if (c.abits[v * W + w] & fr[w]) { hit = true; break; }
+      }
+      uint64_t b = ge_ballot(hit);
+      if (lane == 0) nx[k] = b;
+      any |= b;
+    }
+    ge_sync();
+    if (!any) break;
+    if (lane < W) { vis[lane] |= nx[lane]; fr[lane] = nx[lane]; }
+    ge_sync();
+  }
+  int cnt = 0;
+  for (int w = 0; w < W; w++) cnt += ge_popc64(vis[w]);
+  ge_sync();
+  return cnt == ng;
+}
+
+GE_DEV double ge_pw_leaf(const double *a, int n, int lane) {  // numpy pairwise sum, n <= 128
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; i++) res += a[i];
+    return res;
+  }
+  int lim = n - (n % 8);
+  double r = 0.0;
+  if (lane < 8) { r = a[lane]; for (int i = 8; i < lim; i += 8) r += a[i + lane]; }
+  double r0 = ge_shfl_f64(r, 0), r1 = ge_shfl_f64(r, 1), r2 = ge_shfl_f64(r, 2), r3 = ge_shfl_f64(r, 3);
+  double r4 = ge_shfl_f64(r, 4), r5 = ge_shfl_f64(r, 5), r6 = ge_shfl_f64(r, 6), r7 = ge_shfl_f64(r, 7);
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (int i = lim; i < n; i++) res += a[i];
+  return res;
+}
+template <int D>
+GE_DEV double ge_pw(const double *a, int n, int lane) {
+  if (n <= 128) return ge_pw_leaf(a, n, lane);
+  if constexpr (D > 0) {
+    int n2 = n / 2; n2 -= n2 % 8;
+    double l = ge_pw<D - 1>(a, n2, lane);
+    double r = ge_pw<D - 1>(a + n2, n - n2, lane);
+    return l + r;
+  } else {
+    return 0.0;
+  }
+}
+
+// source node of directed edge idx
+GE_DEV int ge_row_of(const GeParams &P, const GeRctx &c, int idx) {
+  return P.complete ? idx / (P.ng - 1) : (int)c.tmp[idx];
+}
+
+// write weight code for the directed entry u->v (scan of row u)
+GE_DEV void ge_set_code(const GeRctx &c, int u, int v, int code) {
+  for (int k = c.rowptr[u]; k < c.rowptr[u + 1]; k++)
+    if ((c.colw[k] >> 4) == v) { c.colw[k] = (uint16_t)((v << 4) | code); return; }
+}
+
+enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
+
+struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; };
+
+GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
+  const int lane = ge_tid();
+  const int n = P.n, ng = P.ng, W = P.W, m = P.m, E = P.E, F = P.F, T = P.T;
+  const int t = P.env_type;
+  GeRctx c = ge_carve(P);
+  const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
+  int src = 0, dest = -1;
+
+  if (mode != GE_RESET_INJECT) {
+    // ---------------------------------------------------------------- topology (python stream)
+    if (lane == 0) ge_mt_seed_python(c.mt, seed);
+    ge_sync();
+    int pypos = GE_MT_N;
+    const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
+    for (;;) {
+      for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
+      ge_sync();
+      if (P.complete) {  // [nx] complete_graph: sorted rows
+        for (int v = lane; v < ng; v += GE_WAVE)
+          for (int w = 0; w < W; w++) {
+            int lo = w * 64, hi = lo + 64; if (hi > ng) hi = ng;
+            uint64_t bitsw = (hi <= lo) ? 0ull : ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull));
+            if ((v >> 6) == w) bitsw &= ~(1ull << (v & 63));
+            c.abits[v * W + w] = bitsw;
+          }
+      } else {  // [nx] gnm_random_graph: rejection loop, one draw per iteration
+        int cnt = 0, have_u = 0, u = 0;
+        for (;;) {
+          if (pypos >= GE_MT_N) { ge_mt_twist(c.mt, lane); pypos = 0; }
+          if (lane == 0) {
+            while (cnt < m && pypos < GE_MT_N) {
+              uint32_t r = ge_temper(c.mt[pypos++]) >> shift;
+              if (r >= (uint32_t)ng) continue;
+              if (!have_u) { u = (int)r; have_u = 1; continue; }
+              int v = (int)r; have_u = 0;
+              if (u == v) continue;
+              if ((c.abits[u * W + (v >> 6)] >> (v & 63)) & 1ull) continue;
+              c.abits[u * W + (v >> 6)] |= 1ull << (v & 63);
+              c.abits[v * W + (u >> 6)] |= 1ull << (u & 63);
+              c.elist[cnt++] = (uint32_t)u | ((uint32_t)v << 16);
+            }
+          }
+          pypos = ge_shfl_i32(pypos, 0);
+          int cb = ge_shfl_i32(cnt, 0);
+          ge_sync();
+          if (cb >= m) break;
+        }
+      }
+      ge_sync();
+      bool ok = ge_connected(c, ng, W, -1, lane);
+      if (ok && t == GE_TSP) {  // tsp.py:65-71
+        uint64_t deg1 = 0;
+        for (int k = 0; k < W; k++) {
+          int v = k * GE_WAVE + lane; int d = 0;
+          if (v < n) for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]);
+          deg1 |= ge_ballot(v < n && d == 1);
+        }
+        ok = !deg1;
+        if (ok) ok = ge_connected(c, ng, W, 0, lane);
+      }
+      if (ok) break;
+    }
+  } else {
+    // ---------------------------------------------------------------- injected topology
+    for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
+    for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 0;
+    ge_sync();
+    for (int idx = lane; idx < E; idx += GE_WAVE) {
+      int u = (int)inj.links[(ebase + idx) * 2], v = (int)inj.links[(ebase + idx) * 2 + 1];
+      atomicAdd(&c.fill[u], 1);
+      atomicOr((unsigned long long *)&c.abits[u * W + (v >> 6)], (unsigned long long)(1ull << (v & 63)));
+    }
+    ge_sync();
+  }
+
+  // ------------------------------------------------------------------ CSR in insertion order
+  if (mode != GE_RESET_INJECT) {
+    for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
+    ge_sync();
+  }
+  {
+    int carry = 0;
+    for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+      int v = k0 + lane; int d = v < n ? c.fill[v] : 0;
+      int incl = ge_wave_incl_scan(d, lane);
+      if (v < n) c.rowptr[v] = carry + incl - d;
+      carry += ge_shfl_i32(incl, GE_WAVE - 1);
+    }
+    if (lane == 0) c.rowptr[n] = carry;
+    ge_sync();
+  }
+  if (mode == GE_RESET_INJECT) {
+    for (int idx = lane; idx < E; idx += GE_WAVE) {
+      int u = (int)inj.links[(ebase + idx) * 2], v = (int)inj.links[(ebase + idx) * 2 + 1];
+      c.colw[idx] = (uint16_t)((v << 4) | (inj.wcode[ebase + idx] & 15));
+      if (!P.complete) c.tmp[idx] = (uint32_t)u;
+    }
+    ge_sync();
+  } else if (P.complete) {
+    for (int idx = lane; idx < E; idx += GE_WAVE) {
+      int u = idx / (ng - 1), k = idx % (ng - 1);
+      int v = k < u ? k : k + 1;
+      c.colw[idx] = (uint16_t)((v << 4) | 10);
+    }
+    ge_sync();
+  } else {
+    for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 0;
+    ge_sync();
+    for (int id = lane; id < m; id += GE_WAVE) {
+      uint32_t e = c.elist[id]; int u = (int)(e & 0xffffu), v = (int)(e >> 16);
+      int s = c.rowptr[u] + atomicAdd(&c.fill[u], 1); c.tmp[s] = ((uint32_t)id << 16) | (uint32_t)v;
+      int s2 = c.rowptr[v] + atomicAdd(&c.fill[v], 1); c.tmp[s2] = ((uint32_t)id << 16) | (uint32_t)u;
+    }
+    ge_sync();
+    for (int v = lane; v < n; v += GE_WAVE) {  // order each row by edge id == insertion order
+      int lo = c.rowptr[v], hi = c.rowptr[v + 1];
+      for (int a = lo + 1; a < hi; a++) {
+        uint32_t key = c.tmp[a]; int b = a - 1;
+        while (b >= lo && c.tmp[b] > key) { c.tmp[b + 1] = c.tmp[b]; b--; }
+        c.tmp[b + 1] = key;
+      }
+    }
+    ge_sync();
+    for (int idx = lane; idx < E; idx += GE_WAVE) c.colw[idx] = (uint16_t)(((c.tmp[idx] & 0xffffu) << 4) | 10u);
+    ge_sync();
+    for (int v = lane; v < n; v += GE_WAVE) for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) c.tmp[k] = (uint32_t)v;
+    ge_sync();
+  }
+
+  // ------------------------------------------------------------------ weights + terminals (numpy stream)
+  if (mode != GE_RESET_INJECT) {
+    const bool needs_np = (t != GE_DENSEST_SUBGRAPH);
+    int nppos = GE_MT_N;
+    if (needs_np) { if (lane == 0) ge_mt_seed_numpy(c.mt, seed); ge_sync(); }
+    int64_t total = 0;  // masked-rejection draws of randint(3, 10)
+    if (P.weighted) {
+      if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) total = (int64_t)n * n;
+      else if (t == GE_TSP) total = m;
+      else if (t == GE_MAX_INDEPENDENT_SET) total = n;
+    }
+    if (t == GE_TSP && P.weighted) {  // G.edges order: u ascending, insertion order, v > u (tsp.py:88-90)
+      int carry = 0;
+      for (int k0 = 0; k0 < E; k0 += GE_WAVE) {
+        int idx = k0 + lane; int fl = 0;
+        if (idx < E) fl = ((int)(c.colw[idx] >> 4) > ge_row_of(P, c, idx)) ? 1 : 0;
+        int incl = ge_wave_incl_scan(fl, lane);
+        if (fl) c.elist[carry + incl - 1] = (uint32_t)idx;
+        carry += ge_shfl_i32(incl, GE_WAVE - 1);
+      }
+      ge_sync();
+    }
+    if (t == GE_MAX_INDEPENDENT_SET) { for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 10; ge_sync(); }
+    int64_t base = 0;
+    while (base < total) {
+      if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
+      int p = nppos + lane; bool valid = p < GE_MT_N;
+      uint32_t val = valid ? (ge_temper(c.mt[p]) & 7u) : 8u;
+      bool acc = valid && val <= 6u;
+      uint64_t bal = ge_ballot(acc);
+      int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
+      int64_t idx = base + rank;
+      if (acc && idx < total) {
+        int code = 3 + (int)val;
+        if (t == GE_MAX_INDEPENDENT_SET) c.fill[(int)idx] = code;
+        else if (t == GE_TSP) {
+          int k = (int)c.elist[(int)idx]; int u = ge_row_of(P, c, k), v = (int)(c.colw[k] >> 4);
+          c.colw[k] = (uint16_t)((v << 4) | code);
+          ge_set_code(c, v, u, code);
+        } else {
+          int i = (int)(idx / n), j = (int)(idx % n);
+          if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) { ge_set_code(c, i, j, code); ge_set_code(c, j, i, code); }
+        }
+      }
+      int nacc = ge_popc64(bal);
+      if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
+        int need = (int)(total - base - 1);
+        uint64_t lastb = ge_ballot(acc && rank == need);
+        nppos += ge_ctz64(lastb) + 1;
+        base = total;
+      } else {
+        base += nacc;
+        nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+      }
+      ge_sync();
+    }
+    // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane
+    int kterm = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) ? 2 : (t == GE_STEINER_TREE ? P.n_dests + 1 : 0);
+    if (kterm) {
+      for (int v = lane; v < n; v += GE_WAVE) c.perm[v] = v;
+      ge_sync();
+      int i = n - 1;
+      for (;;) {
+        if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
+        if (lane == 0) {
+          while (i >= 1 && nppos < GE_MT_N) {
+            uint32_t j = ge_temper(c.mt[nppos++]) & ge_mask_below((uint32_t)i);
+            if (j > (uint32_t)i) continue;
+            int tv = c.perm[i]; c.perm[i] = c.perm[(int)j]; c.perm[(int)j] = tv;
+            i--;
+          }
+        }
+        nppos = ge_shfl_i32(nppos, 0);
+        int ib = ge_shfl_i32(i, 0);
+        ge_sync();
+        if (ib < 1) break;
+      }
+      src = c.perm[0]; dest = c.perm[1];
+    }
+  } else {
+    if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) {
+      for (int k = lane; k < T; k += GE_WAVE) c.perm[k] = inj.terminals[(int64_t)env * T + k];
+      ge_sync();
+      src = c.perm[0]; dest = c.perm[1];
+    }
+  }
+  if (t == GE_TSP) { src = 0; dest = -1; }
+
+  // ------------------------------------------------------------------ baselines (is_eval_env)
+  double heuristic = 0.0;
+  if (mode != GE_RESET_INJECT && P.is_eval) {
+    const double kNaN = __builtin_nan("");
+    if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || (t == GE_STEINER_TREE && P.n_dests == 1)) {
+      // [nx] dijkstra: least fixpoint of d[u] = min_v fl(d[v] + w(v,u)); Jacobi sweeps in LDS
+      for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = (v == src) ? 0.0 : __builtin_inf();
+      ge_sync();
+      for (int it = 0; it < n; it++) {
+        uint64_t any = 0;
+        for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+          int v = k0 + lane; bool ch = false;
+          if (v < n) {
+            double best = c.sigma[v];
+            for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
+              double d = c.sigma[c.colw[k] >> 4] + ge_wlut(c.colw[k] & 15);
+              if (d < best) { best = d; ch = true; }
+            }
+            c.delta[v] = best;
+          }
+          any |= ge_ballot(ch);
+        }
+        ge_sync();
+        for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = c.delta[v];
+        ge_sync();
+        if (!any) break;
+      }
+      double d = c.sigma[dest];
+      heuristic = (t == GE_LONGEST_PATH) ? -d : d;
+      ge_sync();
+    } else if (t == GE_STEINER_TREE && P.n_dests == n - 1) {
+      // steiner_tree.py:80-81 MST total: Prim on integer codes, summed in ascending order
+      for (int v = lane; v < n; v += GE_WAVE) c.dist[v] = (v == 0) ? 0 : 255;
+      if (lane < 16) c.misc[lane] = 0;
+      uint64_t *intree = c.bits;
+      if (lane < W) intree[lane] = 0ull;
+      ge_sync();
+      for (int it = 0; it < n; it++) {
+        uint32_t best = 0xffffffffu;
+        for (int v = lane; v < n; v += GE_WAVE)
+          if (!((intree[v >> 6] >> (v & 63)) & 1ull)) { uint32_t key = ((uint32_t)c.dist[v] << 16) | (uint32_t)v; if (key < best) best = key; }
+        for (int off = 32; off >= 1; off >>= 1) { uint32_t o = ge_shfl_u32(best, lane ^ off); if (o < best) best = o; }
+        int pick = (int)(best & 0xffffu), code = (int)(best >> 16);
+        ge_sync();
+        if (lane == 0) { intree[pick >> 6] |= 1ull << (pick & 63); if (it) c.misc[code & 15]++; }
+        ge_sync();
+        for (int k = c.rowptr[pick] + lane; k < c.rowptr[pick + 1]; k += GE_WAVE) {
+          int u = c.colw[k] >> 4, cd = c.colw[k] & 15;
+          if (!((intree[u >> 6] >> (u & 63)) & 1ull) && cd < c.dist[u]) c.dist[u] = cd;
+        }
+        ge_sync();
+      }
+      double s = 0.0;
+      for (int code = 3; code <= 10; code++) for (int r = 0; r < c.misc[code]; r++) s += ge_wlut(code);
+      heuristic = s;
+      ge_sync();
+    } else if (t == GE_DENSEST_SUBGRAPH) heuristic = -1.0;             // densest_subgraph.py:85-88
+    else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : kNaN;  // greedy MIS not built
+    else heuristic = kNaN;                                              // Kou / Christofides not built
+  }
+
+  // ------------------------------------------------------------------ structural features
+  if (mode != GE_RESET_INJECT) {
+    // rows sorted by column (scipy canonical CSR) for pagerank
+    for (int idx = lane; idx < E; idx += GE_WAVE) c.scw[idx] = c.colw[idx];
+    ge_sync();
+    for (int v = lane; v < n; v += GE_WAVE) {
+      int lo = c.rowptr[v], hi = c.rowptr[v + 1];
+      for (int a = lo + 1; a < hi; a++) {
+        uint16_t key = c.scw[a]; int b = a - 1;
+        while (b >= lo && c.scw[b] > key) { c.scw[b + 1] = c.scw[b]; b--; }
+        c.scw[b + 1] = key;
+      }
+    }
+    for (int v = lane; v < n; v += GE_WAVE) c.bc[v] = 0.0;
+    ge_sync();
+    // Brandes betweenness + closeness: one level-synchronous BFS per source
+    for (int s = 0; s < n; s++) {
+      for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
+      ge_sync();
+      int d = 0, reach = 1; int64_t tot = 0;
+      for (;;) {  // forward: discover level d+1, sigma by pull from level d
+        // a node moves from -1 to d+1, never to d, so lanes still testing dist[u] == d are unaffected
+        uint64_t any = 0; int found = 0;
+        for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+          int v = k0 + lane; bool hit = false;
+          if (v < n && c.dist[v] < 0) {
+            double sg = 0.0;
+            for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int u = c.colw[k] >> 4; if (c.dist[u] == d) { sg += c.sigma[u]; hit = true; } }
+            if (hit) { c.sigma[v] = sg; c.dist[v] = d + 1; }
+          }
+          uint64_t b = ge_ballot(hit);
+          any |= b; found += ge_popc64(b);
+        }
+        ge_sync();
+        if (!any) break;
+        d++; reach += found; tot += (int64_t)d * found;
+      }
+      for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
+        for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev) { c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bc[v] += c.delta[v]; }
+        ge_sync();
+        for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev - 1) {
+          double acc = 0.0, sv = c.sigma[v];
+          for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int w = c.colw[k] >> 4; if (c.dist[w] == lev) acc += sv * c.coeff[w]; }
+          c.delta[v] = acc;
+        }
+        ge_sync();
+      }
+      if (lane == 0) {  // closeness_centrality, wf_improved
+        double cc = 0.0;
+        if (tot > 0 && n > 1) { cc = ((double)reach - 1.0) / (double)tot; double sc = ((double)reach - 1.0) / (double)(n - 1); cc *= sc; }
+        c.clos[s] = cc;
+      }
+      ge_sync();
+    }
+    if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
+    // clustering (directed formula on the symmetric graph) -> coeff[]
+    for (int i = lane; i < n; i += GE_WAVE) {
+      int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
+      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) { int j = c.colw[k] >> 4; for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]); }
+      int64_t t8 = 8 * common, dt = 2 * dg, db = dg;
+      c.coeff[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
+    }
+    // pagerank ([nx] _pagerank_scipy): pull over in-neighbours in ascending order
+    const bool prw = (t == GE_TSP);
+    const double pinit = 1.0 / (double)n;
+    int ndang = 0;
+    for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+      int i = k0 + lane; bool dang = false;
+      if (i < n) {
+        double S = 0.0;
+        for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? ge_wlut(c.scw[k] & 15) : 1.0) * 1.0;
+        c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
+        c.prx[i] = pinit;
+        dang = (c.rowptr[i + 1] == c.rowptr[i]);
+      }
+      ndang += ge_popc64(ge_ballot(dang));
+    }
+    ge_sync();
+    const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
+    bool conv = false;
+    for (int it = 0; it < 100 && !conv; it++) {
+      double dsum = 0.0;
+      if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
+      for (int i = lane; i < n; i += GE_WAVE) {
+        double acc = 0.0;
+        for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
+          int j = c.scw[k] >> 4;
+          double dat = c.sinv[j] * (prw ? ge_wlut(c.scw[k] & 15) : 1.0);
+          acc += dat * c.prx[j];
+        }
+        double xn = alpha * (acc + dsum * pinit) + oma * pinit;
+        c.prn[i] = xn;
+        c.diff[i] = __builtin_fabs(xn - c.prx[i]);
+      }
+      ge_sync();
+      double err = ge_pw<5>(c.diff, n, lane);
+      for (int i = lane; i < n; i += GE_WAVE) c.prx[i] = c.prn[i];
+      ge_sync();
+      if (err < (double)n * tol) conv = true;
+    }
+  }
+
+  // ------------------------------------------------------------------ write the slot to HBM
+  const ge_buffers &G = P.buf;
+  const int64_t Ne = (int64_t)P.B * E;
+  uint64_t *tbits = c.bits + 3 * W;  // target set
+  if (lane < W) {
+    uint64_t tb = 0;
+    if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) { if ((dest >> 6) == lane) tb = 1ull << (dest & 63); }
+    else if (t == GE_STEINER_TREE) for (int k = 1; k <= P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
+    tbits[lane] = tb;
+  }
+  ge_sync();
+  for (int idx = lane; idx < n * F; idx += GE_WAVE) {
+    int v = idx / F, col = idx % F; float val;
+    if (mode == GE_RESET_INJECT) val = inj.x[nbase * F + idx];
+    else if (col >= P.nflag) {
+      int f = col - P.nflag;
+      double dv = f == 0 ? 2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]) : f == 1 ? c.bc[v] : f == 2 ? c.clos[v] : f == 3 ? c.prx[v] : c.coeff[v];
+      val = (float)dv;
+    } else {
+      val = 0.f;
+      bool is_t = (tbits[v >> 6] >> (v & 63)) & 1ull;
+      if (t == GE_SHORTEST_PATH || t == GE_STEINER_TREE) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : 0.f);
+      else if (t == GE_LONGEST_PATH) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : ((P.parenting == 0 && v == src) ? 2.f : 0.f));
+      else if (t == GE_TSP) val = (col == 1 && v == 0) ? 1.f : 0.f;
+      else if (t == GE_MAX_INDEPENDENT_SET) val = (col == 0) ? (float)ge_wlut(c.fill[v]) : 0.f;
+    }
+    G.x[nbase * F + idx] = val;
+  }
+  for (int idx = lane; idx < E; idx += GE_WAVE) {
+    int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4, code = c.colw[idx] & 15;
+    G.edge_index[ebase + idx] = nbase + u;
+    G.edge_index[Ne + ebase + idx] = nbase + v;
+    float wv = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 1.f : (float)ge_wlut(code);
+    if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
+    else G.edge_attr[ebase + idx] = wv;
+    G.colw[ebase + idx] = c.colw[idx];
+    if (G.rev_edge) { int r = -1; for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) if ((c.colw[k] >> 4) == u) { r = k; break; } G.rev_edge[ebase + idx] = r; }
+  }
+  for (int v = lane; v <= n; v += GE_WAVE) G.row_ptr[(int64_t)env * (n + 1) + v] = c.rowptr[v];
+  for (int i = lane; i < n * W; i += GE_WAVE) G.adj_bits[nbase * W + i] = c.abits[i];
+  // first mask (reset() -> info['mask'])
+  const int A = P.A, AW = P.AW;
+  const bool node_started = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+  for (int w = lane; w < AW; w += GE_WAVE) {
+    uint64_t mb;
+    int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;
+    uint64_t full = (hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull);
+    if (t == GE_SHORTEST_PATH || (t == GE_LONGEST_PATH && P.parenting != 0) || t == GE_TSP) mb = c.abits[src * W + w];
+    else if (t == GE_STEINER_TREE) {  // edges leaving src: steiner_tree.py:116-120
+      int a = c.rowptr[src], b = c.rowptr[src + 1]; mb = 0;
+      int l2 = a > lo ? a : lo, h2 = b < hi ? b : hi;
+      if (h2 > l2) mb = ((h2 - l2 == 64) ? ~0ull : ((1ull << (h2 - l2)) - 1ull)) << (l2 - lo);
+    } else mb = full;  // LP parenting 0, Densest first step, MIS
+    G.mask_bits[(int64_t)env * AW + w] = mb;
+    ((uint64_t *)c.sigma)[w] = mb;  // staged for the byte expansion below (sigma is free now)
+  }
+  ge_sync();
+  for (int idx = lane; idx < A; idx += GE_WAVE) G.mask[(int64_t)env * A + idx] = (uint8_t)((((uint64_t *)c.sigma)[idx >> 6] >> (idx & 63)) & 1ull);
+  for (int w = lane; w < W; w += GE_WAVE) {
+    uint64_t nb = 0;
+    if (node_started && (src >> 6) == w) nb = 1ull << (src & 63);
+    G.node_bits[(int64_t)env * W + w] = nb;
+    G.target_bits[(int64_t)env * W + w] = tbits[w];
+  }
+  for (int k = lane; k < T; k += GE_WAVE) G.terminals[(int64_t)env * T + k] = (t == GE_TSP) ? 0 : ((t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : c.perm[k]);
+  if (lane == 0) {
+    G.head[env] = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : src;
+    G.cost[env] = 0.0; G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
+    G.status[env] = 0; G.heuristic[env] = heuristic;
+    if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
+  }
+  ge_sync();
+}
+
+GE_KERNEL ge_k_reset(GeParams P, const uint32_t *seeds, int mode, int counter_slot, GeInject inj) {
+  int count = (mode == GE_RESET_QUEUE) ? P.buf.reset_count[counter_slot] : P.B;
+  for (int q = ge_bid(); q < count; q += ge_gdim()) {
+    int env = (mode == GE_RESET_QUEUE) ? P.buf.reset_list[q] : q;
+    uint32_t seed = (mode == GE_RESET_ALL) ? seeds[env] : ((mode == GE_RESET_QUEUE) ? P.buf.seed[env] : 0u);
+    ge_reset_env(P, env, seed, mode, inj);
+  }
+}

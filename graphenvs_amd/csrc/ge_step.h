@@ -1,0 +1,285 @@
+// Step kernel: one thread advances one env slot; a workgroup of 256 slots stages its new action
+// masks in LDS and writes the bool mask slab with coalesced 8-byte stores.  Replaces step() and
+// _get_mask() of the six reference envs (shortest_path.py:101-141, longest_path.py:121-196,
+// steiner_tree.py:116-157, tsp.py:170-258, densest_subgraph.py:101-196,
+// max_independent_set.py:92-124).
+#pragma once
+#include "ge_params.h"
+#include "ge_platform.h"
+#include "ge_reset.h"
+
+GE_DEV uint64_t ge_full_word(int A, int w) {
+  int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;
+  if (hi <= lo) return 0ull;
+  return (hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull);
+}
+
+// weight code of the directed edge u -> a inside slot `env` (scan of row u; direct for complete graphs)
+GE_DEV int ge_edge_code(const GeParams &P, int env, int u, int a) {
+  const int32_t *rp = P.buf.row_ptr + (int64_t)env * (P.n + 1);
+  const uint16_t *cw = P.buf.colw + (int64_t)env * P.E;
+  int r0 = rp[u], r1 = rp[u + 1];
+  if (P.complete) { int k = r0 + (a < u ? a : a - 1); return (k < r1 && (cw[k] >> 4) == a) ? (cw[k] & 15) : -1; }
+  for (int k = r0; k < r1; k++) { uint16_t e = cw[k]; if ((e >> 4) == a) return e & 15; }
+  return -1;
+}
+
+GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int counter_slot) {
+  const ge_buffers &G = P.buf;
+  const int tid = ge_tid();
+  const int i0 = ge_bid() * ge_bdim();
+  const int i = i0 + tid;
+  const int n = P.n, W = P.W, F = P.F, A = P.A, AW = P.AW, t = P.env_type;
+  uint64_t *stage = (uint64_t *)ge_dyn_smem();  // [blockDim][W] new node masks (node-action envs)
+  const bool edge_mask = (t == GE_STEINER_TREE);
+  bool wrote_mask = false;  // this slot's node mask changed and sits in `stage`
+
+  if (i == 0) G.reset_count[counter_slot ^ 1] = 0;  // the other counter is idle during this launch
+
+  if (i < P.B) {
+    const int64_t nbase = (int64_t)i * n;
+    int64_t a64 = actions[i];
+    uint8_t st = G.status[i];
+    double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
+    if (st != 0 || a64 == -1) {
+      // frozen slot (finished, autoreset off) or explicit no-op: nothing moves
+    } else {
+      bool in_range = a64 >= 0 && a64 < (int64_t)A;
+      int a = in_range ? (int)a64 : 0;
+      bool mbit = in_range && ((G.mask_bits[(int64_t)i * AW + (a >> 6)] >> (a & 63)) & 1ull);
+      int head = G.head[i];
+      switch (t) {
+        case GE_SHORTEST_PATH:
+        case GE_LONGEST_PATH: {
+          const bool lp = (t == GE_LONGEST_PATH);
+          if (!mbit) { invalid = 1; break; }
+          bool nbr = (G.adj_bits[(nbase + head) * W + (a >> 6)] >> (a & 63)) & 1ull;
+          bool vis_a = (G.node_bits[(int64_t)i * W + (a >> 6)] >> (a & 63)) & 1ull;
+          if (lp && P.parenting >= 1 && (!nbr || vis_a)) { invalid = 1; break; }
+          acted = true;
+          int code = nbr ? ge_edge_code(P, i, head, a) : -1;
+          double wgt = (code >= 0) ? ge_wlut(code) : 0.0;  // adj[head, a] (0 when not adjacent)
+          double cost = G.cost[i];
+          if (lp) { reward = wgt; cost -= wgt; } else { reward = -wgt; cost -= reward; }
+          G.cost[i] = cost;
+          if (lp && (!nbr || vis_a)) {  // longest_path.py:169-173 (parenting 0 only): no state change
+            done = 1; solved = 0; reward = -2.0 * n; break;
+          }
+          int dest = G.terminals[(int64_t)i * P.T + 1];
+          if (a == dest) { done = 1; solved = 1; }
+          G.head[i] = a;
+          G.x[(nbase + a) * F + 0] = 1.f;
+          uint64_t any = 0;
+          for (int w = 0; w < W; w++) {
+            uint64_t vb = G.node_bits[(int64_t)i * W + w];
+            if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
+            uint64_t nm = (lp && P.parenting == 0) ? ge_full_word(A, w) : (G.adj_bits[(nbase + a) * W + w] & ~vb);
+            stage[tid * W + w] = nm; any |= nm;
+          }
+          wrote_mask = !(lp && P.parenting == 0);
+          if (!done && !any) { done = 1; solved = 0; reward = lp ? -2.0 * n : -(double)n; }
+          break;
+        }
+        case GE_TSP: {
+          const int start = 0;
+          if (a64 == start && head == start) {  // tsp.py:203-211
+            acted = true; done = 1; solved = 0; reward = -(double)n; G.cost[i] = -1.0; break;
+          }
+          if (!mbit) { invalid = 1; break; }
+          acted = true;
+          int code = ge_edge_code(P, i, head, a);
+          double wgt = ge_wlut(code);
+          reward = 0.0 - wgt;
+          G.cost[i] = G.cost[i] + wgt;
+          G.x[(nbase + a) * F + 0] = 1.f;
+          G.head[i] = a;
+          int taken = G.counters[i * 2] + 1;
+          G.counters[i * 2] = taken;
+          if (taken == n && a == start) { done = 1; solved = 1; }
+          uint64_t any = 0;
+          for (int w = 0; w < W; w++) {
+            uint64_t vb = G.node_bits[(int64_t)i * W + w];
+            if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
+            uint64_t nm = G.adj_bits[(nbase + a) * W + w] & ~vb;
+            if (taken < n - 1 && w == 0) nm &= ~1ull;  // start only once everything else is taken (tsp.py:178-179)
+            stage[tid * W + w] = nm; any |= nm;
+          }
+          wrote_mask = true;
+          if (!done && !any) { done = 1; reward -= (double)(n * 2); solved = 0; }
+          break;
+        }
+        case GE_STEINER_TREE: {
+          if (!mbit) { invalid = 1; break; }
+          acted = true;
+          const int64_t ebase = (int64_t)i * P.E;
+          const int32_t *rp = G.row_ptr + (int64_t)i * (n + 1);
+          uint16_t e = G.colw[ebase + a];
+          int v = e >> 4;
+          float r = -(float)ge_wlut(e & 15);
+          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;  // numpy float32 accumulator
+          reward = (double)r;
+          G.x[(nbase + v) * F + 0] = 1.f;
+          uint64_t missing = 0;
+          for (int w = 0; w < W; w++) {
+            uint64_t vb = G.node_bits[(int64_t)i * W + w];
+            if ((v >> 6) == w) { vb |= 1ull << (v & 63); G.node_bits[(int64_t)i * W + w] = vb; }
+            missing |= G.target_bits[(int64_t)i * W + w] & ~vb;
+          }
+          if (!missing) { done = 1; solved = 1; }
+          // incremental mask: edges leaving v open towards nodes outside the tree; edges entering v close
+          uint64_t *mb = G.mask_bits + (int64_t)i * AW;
+          uint8_t *mby = G.mask + (int64_t)i * A;
+          for (int k = rp[v]; k < rp[v + 1]; k++) {
+            int u = G.colw[ebase + k] >> 4;
+            bool intree = (G.node_bits[(int64_t)i * W + (u >> 6)] >> (u & 63)) & 1ull;
+            if (!intree) { mb[k >> 6] |= 1ull << (k & 63); mby[k] = 1; }
+            int rk = G.rev_edge[ebase + k];
+            mb[rk >> 6] &= ~(1ull << (rk & 63)); mby[rk] = 0;
+          }
+          break;
+        }
+        case GE_DENSEST_SUBGRAPH: {
+          bool taken_a = in_range && ((G.node_bits[(int64_t)i * W + (a >> 6)] >> (a & 63)) & 1ull);
+          if (!mbit || taken_a) { invalid = 1; break; }
+          acted = true; solved = 1;
+          if (a == n - 1) { reward = 0.0; done = 1; break; }  // stop action: densest_subgraph.py:148-154
+          int k = G.counters[i * 2], ecnt = G.counters[i * 2 + 1], new_edges = 0;
+          uint64_t any = 0;
+          for (int w = 0; w < W; w++) new_edges += ge_popc64(G.adj_bits[(nbase + a) * W + w] & G.node_bits[(int64_t)i * W + w]);
+          reward = (k == 0) ? 0.0 : ((double)(ecnt + new_edges) / (double)(k + 1)) - ((double)ecnt / (double)k);
+          ecnt += new_edges; k += 1;
+          G.counters[i * 2] = k; G.counters[i * 2 + 1] = ecnt;
+          G.x[(nbase + a) * F + 0] = 1.f;
+          G.cost[i] = (double)ecnt / (double)k;
+          for (int w = 0; w < W; w++) {
+            uint64_t vb = G.node_bits[(int64_t)i * W + w];
+            if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
+            uint64_t nm;
+            if (P.parenting == 0) nm = ge_full_word(A, w) & ~vb;
+            else {  // neighbours of the taken set: running union kept in target_bits
+              uint64_t un = G.target_bits[(int64_t)i * W + w] | G.adj_bits[(nbase + a) * W + w];
+              G.target_bits[(int64_t)i * W + w] = un;
+              nm = un & ~vb;
+            }
+            stage[tid * W + w] = nm; any |= nm;
+          }
+          wrote_mask = true;
+          if ((double)k == P.n_choices) done = 1;
+          (void)any;
+          break;
+        }
+        case GE_MAX_INDEPENDENT_SET: {
+          if (!mbit) { invalid = 1; break; }
+          acted = true;
+          float r = -G.x[(nbase + a) * F + 0];
+          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;
+          reward = (double)r;
+          G.x[(nbase + a) * F + 1] = 1.f;
+          uint64_t any = 0;
+          for (int w = 0; w < W; w++) {
+            uint64_t vb = G.node_bits[(int64_t)i * W + w];
+            if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
+            uint64_t nm = ge_full_word(A, w) & ~vb;
+            stage[tid * W + w] = nm; any |= nm;
+          }
+          wrote_mask = true;
+          if (!any) { done = 1; solved = 1; }
+          break;
+        }
+      }
+    }
+    G.reward[i] = reward;
+    G.terminated[i] = (uint8_t)done;
+    G.invalid[i] = (uint8_t)invalid;
+    G.solved[i] = (int8_t)solved;
+    if (acted) {
+      int len = G.counters[i * 2 + (t == GE_DENSEST_SUBGRAPH || t == GE_TSP ? 0 : 1)];
+      if (!(t == GE_DENSEST_SUBGRAPH || t == GE_TSP)) { len += 1; G.counters[i * 2 + 1] = len; }
+      G.tstep[i] = G.tstep[i] + 1;
+      if (done) {
+        G.final_cost[i] = G.cost[i];
+        G.final_heur[i] = G.heuristic[i];
+        G.final_len[i] = len;
+        if (P.autoreset) {
+          int slot = atomicAdd(&G.reset_count[counter_slot], 1);
+          G.reset_list[slot] = i;
+          G.seed[i] = G.seed[i] + (uint32_t)P.seed_stride;
+          G.episode[i] = G.episode[i] + 1;
+          G.status[i] = 2;
+          wrote_mask = false;  // the reset kernel rewrites the whole slot
+        } else {
+          G.status[i] = 1;
+        }
+      }
+    }
+    if (wrote_mask && !edge_mask) for (int w = 0; w < W; w++) G.mask_bits[(int64_t)i * AW + w] = stage[tid * W + w];
+  }
+
+  if (edge_mask) return;  // SteinerTree updates its [B, 2m] mask incrementally above
+  // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
+  uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * W);
+  flag[tid] = wrote_mask ? 1 : 0;
+  ge_sync();
+  int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
+  if (nb <= 0) return;
+  uint8_t *out = G.mask + (int64_t)i0 * A;
+  if ((A & 7) == 0) {
+    int groups = nb * (A >> 3);
+    for (int g = tid; g < groups; g += ge_bdim()) {
+      int e = (g << 3) / A, v0 = (g << 3) % A;
+      if (!flag[e]) continue;
+      uint64_t b8 = (stage[e * W + (v0 >> 6)] >> (v0 & 63)) & 0xffull;
+      uint64_t y = (b8 * 0x0101010101010101ull) & 0x8040201008040201ull;
+      y = ((y + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull;
+      *(uint64_t *)(out + ((int64_t)g << 3)) = y;
+    }
+  } else {
+    int total = nb * A;
+    for (int idx = tid; idx < total; idx += ge_bdim()) {
+      int e = idx / A, v = idx % A;
+      if (!flag[e]) continue;
+      out[idx] = (uint8_t)((stage[e * W + (v >> 6)] >> (v & 63)) & 1ull);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bench / test policy: uniform choice among valid actions, keyed by (policy_seed, global slot, tstep)
+GE_DEV uint64_t ge_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
+  int i = ge_bid() * ge_bdim() + ge_tid();
+  if (i >= P.B) return;
+  const uint64_t *mb = P.buf.mask_bits + (int64_t)i * P.AW;
+  uint32_t cnt = 0;
+  for (int w = 0; w < P.AW; w++) cnt += (uint32_t)ge_popc64(mb[w]);
+  if (!cnt || P.buf.status[i] == 1) { actions[i] = -1; return; }
+  uint64_t gi = (uint64_t)(P.env_index_base + i), ts = (uint64_t)P.buf.tstep[i];
+  uint64_t z = ge_mix64(policy_seed + gi * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
+  uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
+  int64_t act = -1;
+  for (int w = 0; w < P.AW; w++) {
+    uint64_t word = mb[w]; uint32_t pc = (uint32_t)ge_popc64(word);
+    if (r < pc) { for (uint32_t k = 0; k < r; k++) word &= word - 1; act = (int64_t)w * 64 + ge_ctz64(word); break; }
+    r -= pc;
+  }
+  actions[i] = act;
+}
+
+// utils.vectorize_graph for every slot (utils.py:87-88): [x.ravel | edge_attr.ravel | links.ravel] as f32
+GE_KERNEL ge_k_vectorize(GeParams P, float *out) {
+  const int64_t L = (int64_t)P.n * P.F + (int64_t)P.E * P.Fe + 2 * (int64_t)P.E;
+  const int64_t p1 = (int64_t)P.n * P.F, p2 = p1 + (int64_t)P.E * P.Fe;
+  const int64_t total = (int64_t)P.B * L, Ne = (int64_t)P.B * P.E;
+  for (int64_t idx = (int64_t)ge_bid() * ge_bdim() + ge_tid(); idx < total; idx += (int64_t)ge_gdim() * ge_bdim()) {
+    int64_t b = idx / L, j = idx % L; float v;
+    if (j < p1) v = P.buf.x[b * p1 + j];
+    else if (j < p2) v = P.buf.edge_attr[b * (int64_t)P.E * P.Fe + (j - p1)];
+    else { int64_t q = j - p2, e = q >> 1; v = (float)(P.buf.edge_index[(q & 1) * Ne + b * P.E + e] - b * P.n); }
+    out[idx] = v;
+  }
+}

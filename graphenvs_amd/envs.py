@@ -1,0 +1,60 @@
+"""Single-env facade with the reference's numpy surface: ``make(id, **kwargs)`` returns an object whose
+``reset(seed=)`` / ``step(a)`` return what the reference env classes return (flat float32 obs of
+utils.vectorize_graph, ``info['mask']`` as a numpy bool array, done-time info keys), computed by the
+HIP engine with num_envs=1.  Meant for drop-in checks and small runs; throughput lives in
+VectorGraphEnv."""
+import numpy as np
+import torch
+
+from .vector_env import VectorGraphEnv
+
+_F32_REWARD = ("SteinerTree-v0", "MaxIndependentSet-v0")  # steiner_tree.py:137, max_independent_set.py:109
+
+
+class GraphEnv:
+    def __init__(self, env_id, n_nodes, n_edges, device="cuda", _library=None, **kwargs):
+        self.env_id = env_id
+        self._v = VectorGraphEnv(env_id, 1, n_nodes, n_edges, device=device, autoreset=False, obs_mode="flat",
+                                 _library=_library, **kwargs)
+        self.n_nodes, self.n_edges = self._v.n, self._v.m
+        self.action_space = self._v.single_action_space
+        self.observation_space = self._v.single_observation_space
+        self._seed = None
+
+    def _np(self, t):
+        return t.detach().cpu().numpy()
+
+    def reset(self, seed=None, options=None):
+        """reset(seed=s) reproduces the reference's reset(seed=s).  seed=None moves to the slot's next
+        episode seed (the reference would continue the process-global streams instead)."""
+        obs, info = self._v.reset(seed=None if seed is None else [int(seed)])
+        return self._np(obs)[0].copy(), {"mask": self._np(info["mask"])[0].copy()}
+
+    def step(self, action):
+        obs, r, term, trunc, info = self._v.step(torch.tensor([int(action)], dtype=torch.int64))
+        if bool(self._np(info["invalid_action"])[0]):
+            raise AssertionError(f"Mask of {action} is False!")  # shortest_path.py:113
+        done = bool(self._np(term)[0])
+        rew = self._np(r)[0]
+        rew = np.float32(rew) if self.env_id in _F32_REWARD else np.float64(rew)
+        out = {"mask": self._np(info["mask"])[0].copy()}
+        solved = int(self._np(info["solved"])[0])
+        if solved >= 0:
+            out["solved"] = bool(solved)
+        if done or self.env_id == "LongestPath-v0":
+            cost = self._np(self._v.t["cost"])[0]
+            out["solution_cost"] = np.float32(cost) if self.env_id in _F32_REWARD else np.float64(cost)
+            out["heuristic_solution"] = float(self._np(self._v.t["heuristic"])[0])
+        return self._np(obs)[0].copy(), rew, done, False, out
+
+    def close(self):
+        self._v.close()
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+def make(env_id, **kwargs):
+    """gym.make(id, **kwargs) for the six hot-path ids (graph_envs/__init__.py:9-56)."""
+    return GraphEnv(env_id, **kwargs)

@@ -1,0 +1,303 @@
+"""Batched graph environments on one MI355X: the host side of the C ABI.
+
+Mirrors the reference's Gymnasium surface (graph_envs/__init__.py:9-56 and the six env classes):
+same ids, same constructor kwargs/defaults/asserts, ``reset(seed=)`` / ``step(actions)`` /
+``info['mask']``; the observation is the PyG-shaped view of utils.to_pyg_graph (utils.py:26-29)
+kept resident in HBM.  All compute happens in the HIP kernels behind include/graphenvs.h; torch
+is used for device memory and streams only.
+"""
+import ctypes as C
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ENV_IDS = tuple(_lib.ENV_TYPES)
+
+# constructor signatures of the reference
+_DEFAULTS = {
+    "ShortestPath-v0": dict(weighted=True, return_graph_obs=False, parenting=-1, structural_features=True, is_eval_env=False),
+    "LongestPath-v0": dict(weighted=True, return_graph_obs=False, is_eval_env=False, parenting=-1),
+    "SteinerTree-v0": dict(n_dests=3, weighted=True, parenting=-1, is_eval_env=False),
+    "TSP-v0": dict(weighted=True, return_graph_obs=False, parenting=-1, spatial=False, is_eval_env=False),
+    "DensestSubgraph-v0": dict(weighted=False, n_choices=-1, return_graph_obs=False, is_eval_env=False, parenting=-1),
+    "MaxIndependentSet-v0": dict(weighted=True, return_graph_obs=False, is_eval_env=False),
+}
+
+
+def normalize_kwargs(env_id, n_nodes, n_edges, **kwargs):
+    """Apply the reference constructors' defaults and asserts (same messages)."""
+    if env_id not in _DEFAULTS:
+        raise KeyError(f"unknown env id {env_id!r}; hot-path ids are {ENV_IDS}")
+    kw = dict(_DEFAULTS[env_id])
+    for k, v in kwargs.items():
+        if k not in kw:
+            raise TypeError(f"{env_id}.__init__() got an unexpected keyword argument {k!r}")
+        kw[k] = v
+    if env_id == "ShortestPath-v0":
+        assert kw["parenting"] == -1, "Parenting is not available for shortest path"  # shortest_path.py:26
+    if env_id == "LongestPath-v0":
+        assert kw["parenting"] in [0, 1, 2, 3]  # longest_path.py:29
+    if env_id == "SteinerTree-v0":
+        assert kw["parenting"] == -1, "Parenting not available for this environment"  # steiner_tree.py:29
+    if env_id == "TSP-v0":
+        assert kw["parenting"] in [1, 2], "Parenting must be either 1 or 2"  # tsp.py:25
+        if kw["spatial"]:
+            assert kw["weighted"] == True, "Spatial TSP must be weighted"  # noqa: E712  tsp.py:27
+    if env_id == "DensestSubgraph-v0":
+        assert kw["parenting"] in [0, 1], "Parenting must be 0 or 1"  # densest_subgraph.py:28
+        assert kw["weighted"] == False, "Weighted graphs not supported for this env"  # noqa: E712
+    if env_id in ("LongestPath-v0", "DensestSubgraph-v0") and n_edges == -1:
+        n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # longest_path.py:41-42
+    if env_id == "DensestSubgraph-v0" and kw["n_choices"] == -1:
+        kw["n_choices"] = float(n_nodes // np.exp(1))  # densest_subgraph.py:38-39
+    kw["n_nodes"], kw["n_edges"] = int(n_nodes), int(n_edges)
+    return kw
+
+
+class GraphBatch(SimpleNamespace):
+    """PyG ``Batch``-shaped view of the engine's observation slabs (x, edge_index, edge_attr, batch, ptr).
+    Tensors alias engine memory and are valid until the next step()/reset(); ``to_pyg()`` upgrades to a
+    real torch_geometric Batch when that package is installed."""
+
+    def to_pyg(self):
+        from torch_geometric.data import Batch, Data
+        b = Batch(x=self.x, edge_index=self.edge_index, edge_attr=self.edge_attr, batch=self.batch, ptr=self.ptr)
+        b._num_graphs = self.num_graphs
+        return b
+
+    def clone(self):
+        return GraphBatch(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.__dict__.items()})
+
+
+class _Space(SimpleNamespace):
+    pass
+
+
+class VectorGraphEnv:
+    """B independent envs of one id on one GPU.  One instance per process/GPU; no global state."""
+
+    def __init__(self, env_id, num_envs, n_nodes, n_edges, device="cuda", autoreset=True, obs_mode="pyg",
+                 env_index_base=0, seed_stride=None, strict=False, _library=None, **kwargs):
+        self.env_id = env_id
+        self.kwargs = normalize_kwargs(env_id, n_nodes, n_edges, **kwargs)
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self.obs_mode = obs_mode
+        self.strict = strict
+        self.autoreset = bool(autoreset)
+        if _library is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("graphenvs_amd runs on a ROCm GPU only (device='cuda'); there is no CPU path")
+            if not torch.cuda.is_available():
+                raise RuntimeError("graphenvs_amd: no GPU visible to torch (torch.cuda.is_available() is False)")
+            self._L = _lib.load()
+        else:
+            self._L = _library  # CPU sanitizer harness (tests/emu), host memory
+        kw = self.kwargs
+        self.n, self.m = kw["n_nodes"], kw["n_edges"]
+        self.seed_stride = int(seed_stride) if seed_stride is not None else self.num_envs
+        self.env_index_base = int(env_index_base)
+        self.cfg = _lib.GeConfig(
+            _lib.ENV_TYPES[env_id], self.num_envs, self.n, self.m, int(bool(kw.get("weighted", False))),
+            int(kw.get("parenting", -1)), int(kw.get("n_dests", 0)), int(bool(kw.get("spatial", False))),
+            int(bool(kw.get("is_eval_env", False))), int(self.autoreset), float(kw.get("n_choices", -1)),
+            self.env_index_base, self.seed_stride)
+        lay = _lib.GeLayout()
+        _lib.check(self._L, self._L.ge_get_layout(C.byref(self.cfg), C.byref(lay)), "ge_get_layout")
+        self.layout = lay
+        self.F, self.Fe, self.A, self.W, self.E, self.obs_len = lay.F, lay.Fe, lay.A, lay.W, lay.E, int(lay.obs_len)
+        B, n, E, W, A = self.num_envs, self.n, self.E, self.W, self.A
+        AW = (A + 63) // 64
+        T = max(2, kw.get("n_dests", 0) + 1) if env_id == "SteinerTree-v0" else 2
+        self.T = T
+        dev = self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        t = {}
+        t["x"] = z((B * n, self.F), torch.float32)
+        t["edge_index"] = z((2, B * E), torch.int64)
+        t["edge_attr"] = z((B * E, self.Fe), torch.float32)
+        t["row_ptr"] = z((B, n + 1), torch.int32)
+        t["colw"] = z((B * E,), torch.int16)
+        t["adj_bits"] = z((B * n, W), torch.int64)
+        t["rev_edge"] = z((B * E,), torch.int32) if env_id == "SteinerTree-v0" else None
+        t["head"] = z((B,), torch.int32)
+        t["terminals"] = z((B, T), torch.int32)
+        t["node_bits"] = z((B, W), torch.int64)
+        t["target_bits"] = z((B, W), torch.int64)
+        t["cost"] = z((B,), torch.float64)
+        t["counters"] = z((B, 2), torch.int32)
+        t["seed"] = z((B,), torch.int32)
+        t["episode"] = z((B,), torch.int64)
+        t["tstep"] = z((B,), torch.int64)
+        t["status"] = z((B,), torch.uint8)
+        t["heuristic"] = z((B,), torch.float64)
+        t["mask"] = z((B, A), torch.uint8)
+        t["mask_bits"] = z((B, AW), torch.int64)
+        t["reward"] = z((B,), torch.float64)
+        t["terminated"] = z((B,), torch.uint8)
+        t["invalid"] = z((B,), torch.uint8)
+        t["solved"] = z((B,), torch.int8)
+        t["final_cost"] = z((B,), torch.float64)
+        t["final_heur"] = z((B,), torch.float64)
+        t["final_len"] = z((B,), torch.int32)
+        t["reset_list"] = z((B,), torch.int32)
+        t["reset_count"] = z((4,), torch.int32)
+        self.t = t
+        bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in t.items()})
+        h = C.c_void_p()
+        _lib.check(self._L, self._L.ge_create(C.byref(self.cfg), C.byref(bufs), C.byref(h)), "ge_create")
+        self._h = h
+        # static parts of the PyG view
+        self._batch = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(n)
+        self._ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n
+        self._truncated = torch.zeros(B, dtype=torch.bool, device=dev)
+        self._actions_scratch = z((B,), torch.int64)
+        self._flat = None
+        self._was_reset = False
+        self.single_action_space = _Space(n=(self.m if env_id == "SteinerTree-v0" else n), mask_size=A)  # steiner_tree.py:43
+        self.single_observation_space = _Space(shape=(self.obs_len,), dtype=np.float32)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self._L.ge_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ views
+    def graph(self):
+        t = self.t
+        return GraphBatch(x=t["x"], edge_index=t["edge_index"], edge_attr=t["edge_attr"], batch=self._batch,
+                          ptr=self._ptr, num_graphs=self.num_envs)
+
+    def flat_obs(self):
+        """utils.vectorize_graph of every slot: float32 [B, obs_len] (utils.py:87-88)."""
+        if self._flat is None:
+            self._flat = torch.empty((self.num_envs, self.obs_len), dtype=torch.float32, device=self.device)
+        _lib.check(self._L, self._L.ge_vectorize(self._h, self._flat.data_ptr(), self._stream()), "ge_vectorize")
+        return self._flat
+
+    def _obs(self):
+        return self.flat_obs() if self.obs_mode == "flat" else self.graph()
+
+    @property
+    def mask(self):
+        return self.t["mask"].view(torch.bool)
+
+    def _info(self, stepped):
+        t = self.t
+        info = {"mask": self.mask, "mask_bits": t["mask_bits"]}
+        if stepped:
+            info.update(solved=t["solved"], solution_cost=t["final_cost"], heuristic_solution=t["final_heur"],
+                        invalid_action=t["invalid"].view(torch.bool), episode_length=t["final_len"])
+        return info
+
+    # ------------------------------------------------------------------ gym surface
+    def _seed_tensor(self, seed):
+        B = self.num_envs
+        if seed is None:
+            if not self._was_reset:
+                seed = 0
+            else:  # next episode of every slot
+                s = (self.t["seed"].cpu().numpy().view(np.uint32).astype(np.int64) + self.seed_stride) % (1 << 32)
+                return torch.from_numpy(s.astype(np.uint32).view(np.int32)).to(self.device)
+        if isinstance(seed, (int, np.integer)):
+            s = (int(seed) + self.env_index_base + np.arange(B, dtype=np.int64)) % (1 << 32)
+        else:
+            s = np.asarray(seed.cpu() if torch.is_tensor(seed) else seed, dtype=np.int64).reshape(B)
+            assert ((s >= 0) & (s < (1 << 32))).all(), "seeds must be in [0, 2**32) (np.random.seed requirement)"
+        return torch.from_numpy(s.astype(np.uint32).view(np.int32)).to(self.device)
+
+    def reset(self, seed=None, options=None):
+        """reset(seed=s): slot i (global index g) runs the reference's reset(seed=(s+g) mod 2^32); a
+        sequence/tensor gives every slot its own seed."""
+        seeds = self._seed_tensor(seed)
+        self._seeds_keepalive = seeds
+        _lib.check(self._L, self._L.ge_reset(self._h, seeds.data_ptr(), self._stream()), "ge_reset")
+        self._was_reset = True
+        return self._obs(), self._info(False)
+
+    def step(self, actions):
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions, dtype=np.int64))
+        actions = actions.to(device=self.device, dtype=torch.int64).contiguous()
+        assert actions.shape == (self.num_envs,)
+        self._act_keepalive = actions
+        _lib.check(self._L, self._L.ge_step(self._h, actions.data_ptr(), self._stream()), "ge_step")
+        t = self.t
+        if self.strict and bool(t["invalid"].any()):
+            bad = torch.nonzero(t["invalid"]).flatten().tolist()
+            raise AssertionError(f"invalid action in slots {bad[:8]} (the reference asserts here)")
+        return self._obs(), t["reward"], t["terminated"].view(torch.bool), self._truncated, self._info(True)
+
+    # ------------------------------------------------------------------ extras
+    def sample_random_actions(self, policy_seed=0, out=None):
+        out = self._actions_scratch if out is None else out
+        _lib.check(self._L, self._L.ge_sample_actions(self._h, int(policy_seed), out.data_ptr(), self._stream()),
+                   "ge_sample_actions")
+        return out
+
+    def random_rollout(self, n_steps, policy_seed=0):
+        _lib.check(self._L, self._L.ge_random_rollout(self._h, int(policy_seed), int(n_steps),
+                                                      self._actions_scratch.data_ptr(), self._stream()),
+                   "ge_random_rollout")
+
+    def timed_rollout(self, n_steps, policy_seed=0):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self._L, self._L.ge_timed_rollout(self._h, int(policy_seed), int(n_steps),
+                                                     self._actions_scratch.data_ptr(), self._stream(),
+                                                     C.byref(a), C.byref(b), C.byref(c)), "ge_timed_rollout")
+        return dict(step_ms=a.value, reset_ms=b.value, policy_ms=c.value)
+
+    def inject_state(self, links, wcode, x, terminals=None):
+        """Parity path: load post-reset states produced elsewhere (links [B,E,2] local ids, wcode [B,E] in
+        {3..10}, x [B,n,F], terminals [B,T])."""
+        dev = self.device
+        links = torch.as_tensor(np.asarray(links), dtype=torch.int64).to(dev).contiguous()
+        wcode = torch.as_tensor(np.asarray(wcode), dtype=torch.uint8).to(dev).contiguous()
+        x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dev).contiguous()
+        term = None
+        if terminals is not None:
+            term = torch.as_tensor(np.asarray(terminals), dtype=torch.int32).to(dev).contiguous()
+            assert term.shape == (self.num_envs, self.T)
+        assert links.shape == (self.num_envs, self.E, 2) and wcode.shape == (self.num_envs, self.E)
+        assert x.shape == (self.num_envs, self.n, self.F)
+        self._inj_keepalive = (links, wcode, x, term)
+        _lib.check(self._L, self._L.ge_inject_state(self._h, links.data_ptr(), wcode.data_ptr(), x.data_ptr(),
+                                                    term.data_ptr() if term is not None else None, self._stream()),
+                   "ge_inject_state")
+        self._was_reset = True
+        return self._obs(), self._info(False)
+
+    def state_dict(self):
+        return {k: v.clone() for k, v in self.t.items() if v is not None}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            self.t[k].copy_(v)
+
+    def edge_links(self):
+        """[B, E, 2] local node ids (GraphInstance.edge_links of every slot)."""
+        ei = self.t["edge_index"].view(2, self.num_envs, self.E)
+        off = (torch.arange(self.num_envs, device=self.device, dtype=torch.int64) * self.n).view(1, -1, 1)
+        return (ei - off).permute(1, 2, 0).contiguous()
+
+
+def make_vec(env_id, num_envs, **kwargs):
+    return VectorGraphEnv(env_id, num_envs, **kwargs)

@@ -1,0 +1,164 @@
+/*
+ * graphenvs.h -- C ABI of the MI355X-native batched graph-env engine (libgraphenvs_hip.so).
+ *
+ * Drop-in boundary for the reference's hot path (teshnizi/GraphEnvs): the reference has no
+ * FFI; its boundary is the Gymnasium protocol of six env classes.  Each entry point below
+ * names the reference interface it replaces (paths under /root/reference/graph_envs/).
+ *
+ * Conventions
+ *  - plain C types only; every buffer pointer is a DEVICE pointer owned by the caller
+ *    (the Python host allocates them with torch); the library never allocates device memory;
+ *  - every launch goes to the hipStream_t passed as `stream` (void*, NULL = default stream);
+ *    no call synchronises the stream or the device;
+ *  - int return code: GE_OK or a negative GE_E_* value; no exceptions cross the ABI;
+ *  - gfx950 only.
+ */
+#ifndef GRAPHENVS_H
+#define GRAPHENVS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GE_ABI_VERSION 1
+
+/* env ids of graph_envs/__init__.py:9-56 that are on the hot path */
+enum {
+  GE_SHORTEST_PATH = 0,       /* shortest_path.py  ShortestPathEnv   */
+  GE_LONGEST_PATH = 1,        /* longest_path.py   LongestPathEnv    */
+  GE_STEINER_TREE = 2,        /* steiner_tree.py   SteinerTreeEnv    */
+  GE_TSP = 3,                 /* tsp.py            TSPEnv            */
+  GE_DENSEST_SUBGRAPH = 4,    /* densest_subgraph.py DensestSubgraphEnv */
+  GE_MAX_INDEPENDENT_SET = 5  /* max_independent_set.py MaxIndependentSet */
+};
+
+enum {
+  GE_OK = 0,
+  GE_E_BADARG = -1,      /* invalid config / null pointer */
+  GE_E_UNSUPPORTED = -2, /* valid in the reference but not built yet */
+  GE_E_LAUNCH = -3,      /* HIP launch/runtime error (hipGetLastError) */
+  GE_E_TOOBIG = -4       /* per-env graph does not fit the LDS-resident reset kernel */
+};
+
+/* Constructor kwargs of the reference env classes, plus batch geometry.
+ * shortest_path.py:23, longest_path.py:26, steiner_tree.py:26, tsp.py:22,
+ * densest_subgraph.py:25, max_independent_set.py:25. */
+typedef struct {
+  int32_t env_type;
+  int32_t num_envs;        /* B: env slots on this GPU */
+  int32_t n_nodes;         /* uniform geometry */
+  int32_t n_edges;         /* undirected edge count m (E = 2m directed) */
+  int32_t weighted;
+  int32_t parenting;
+  int32_t n_dests;         /* SteinerTree */
+  int32_t spatial;         /* TSP (not built yet -> GE_E_UNSUPPORTED) */
+  int32_t is_eval_env;
+  int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset */
+  double n_choices;        /* DensestSubgraph; < 0 -> floor(n / e) as densest_subgraph.py:38-39 */
+  int64_t env_index_base;  /* global index of slot 0 (multi-GPU shard of the batch dimension) */
+  int64_t seed_stride;     /* episode k of a slot seeded s0 runs reset(seed=(s0 + k*seed_stride) mod 2^32) */
+} ge_config;
+
+/* Sizes (in elements) of every caller-allocated device buffer for a config. */
+typedef struct {
+  int32_t F, Fe, A, W, E;      /* node feats, edge feats, mask length per env, u64 words per node set, directed edges */
+  int64_t total_nodes, total_edges;
+  int64_t obs_len;             /* flat obs length per env: n*F + E*Fe + 2E (utils.py:87-88) */
+  int64_t reset_lds_bytes;     /* dynamic LDS one reset workgroup needs */
+} ge_layout;
+
+/* Device buffers.  B = num_envs, Nn = B*n, Ne = B*E, W = ceil(n/64).
+ * Observation slabs are kept in PyG layout (utils.py:26-29 to_pyg_graph): */
+typedef struct {
+  /* --- observation (PyG Batch layout) */
+  float *x;             /* [Nn, F]   GraphInstance.nodes of every env, row = global node id */
+  int64_t *edge_index;  /* [2, Ne]   edge_links transposed, node ids offset by slot*n       */
+  float *edge_attr;     /* [Ne, Fe]  GraphInstance.edges                                    */
+  /* --- graph slab (CSR, insertion-order columns) */
+  int32_t *row_ptr;     /* [B, n+1]  local offsets into the slot's edge segment             */
+  uint16_t *colw;       /* [Ne]      (col << 4) | weight code k, weight = k/10.0 (k=10: 1.0) */
+  uint64_t *adj_bits;   /* [Nn, W]   adjacency bit rows                                     */
+  int32_t *rev_edge;    /* [Ne]      SteinerTree: local index of the reverse directed edge (else NULL) */
+  /* --- per-slot dynamic state */
+  int32_t *head;        /* [B]  path head / TSP head                                        */
+  int32_t *terminals;   /* [B, T] T = max(2, n_dests+1): src, dest(s)                        */
+  uint64_t *node_bits;  /* [B, W] visited / in-tree / taken set                              */
+  uint64_t *target_bits;/* [B, W] SteinerTree: targets                                       */
+  double *cost;         /* [B]  solution_cost accumulator (f32 semantics for Steiner/MIS)    */
+  int32_t *counters;    /* [B, 2] taken count, edge count (Densest) / steps in episode       */
+  uint32_t *seed;       /* [B]  seed of the slot's current episode                           */
+  int64_t *episode;     /* [B]  episode index k of the slot                                  */
+  int64_t *tstep;       /* [B]  transitions executed by the slot since creation              */
+  uint8_t *status;      /* [B]  0 = running, 1 = finished (autoreset off), 2 = needs reset   */
+  double *heuristic;    /* [B]  heuristic_solution of the current episode (is_eval_env)      */
+  /* --- outputs of the last step / reset */
+  uint8_t *mask;        /* [B, A] info['mask'] as bool bytes                                 */
+  uint64_t *mask_bits;  /* [B, ceil(A/64)] same, packed                                      */
+  double *reward;       /* [B]                                                               */
+  uint8_t *terminated;  /* [B]                                                               */
+  uint8_t *invalid;     /* [B]  1 where the reference would have raised AssertionError       */
+  int8_t *solved;       /* [B]  info['solved']: -1 absent, 0/1                               */
+  double *final_cost;   /* [B]  info['solution_cost'] where terminated                       */
+  double *final_heur;   /* [B]  info['heuristic_solution'] where terminated                  */
+  int32_t *final_len;   /* [B]  episode length where terminated                              */
+  /* --- reset work queue */
+  int32_t *reset_list;  /* [B]                                                               */
+  int32_t *reset_count; /* [4]  [0] = entries in reset_list                                  */
+} ge_buffers;
+
+typedef struct ge_engine ge_engine;
+
+int ge_abi_version(void);
+
+/* sizes for a config; replaces the observation_space/action_space arithmetic of the
+ * constructors (shortest_path.py:40-42, steiner_tree.py:43-45, tsp.py:41-42). */
+int ge_get_layout(const ge_config *cfg, ge_layout *out);
+
+/* gym.make(id, **kwargs) for a batch (graph_envs/__init__.py:9-56 + the constructors). */
+int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out);
+int ge_destroy(ge_engine *e);
+
+/* env.reset(seed=s) for every slot (shortest_path.py:47-98 and the five siblings):
+ * seeds [B] uint32 on device = first-episode seed per slot; sets episode = 0.
+ * Runs graph sampling, weights (a8), terminals (a9), structural features (a6),
+ * baselines (a16), first mask; fills the observation slabs. */
+int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream);
+
+/* env.step(a) for every slot (shortest_path.py:111-141 and siblings).  actions [B] int64 on
+ * device.  Writes reward/terminated/invalid/solved/final_* and the next mask; with autoreset
+ * it then regenerates finished slots with the seed of their next episode. */
+int ge_step(ge_engine *e, const int64_t *actions, void *stream);
+
+/* the two halves of ge_step, exposed for profiling and for callers that overlap them */
+int ge_step_only(ge_engine *e, const int64_t *actions, void *stream);
+int ge_reset_pending(ge_engine *e, void *stream);
+
+/* Parity path: load a post-reset state produced elsewhere instead of sampling it
+ * (SURVEY 7 "injecting the oracle's post-reset state").  links [B,E,2] int64 local node ids in
+ * edge_links order, wcode [B,E] uint8 weight codes, x [B,n,F] float32, terminals [B,T] int32. */
+int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
+                    const int32_t *terminals, void *stream);
+
+/* utils.vectorize_graph for the whole batch (utils.py:87-88): out [B, obs_len] float32. */
+int ge_vectorize(ge_engine *e, float *out, void *stream);
+
+/* Uniform random valid action per slot from mask_bits (bench/test policy; the same function is
+ * restated in oracle/ge_oracle.c oge_policy_pick).  actions [B] int64; -1 where the mask is empty. */
+int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream);
+
+/* n_steps x (sample, step[, autoreset]) without host involvement between launches. */
+int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *actions_scratch,
+                      void *stream);
+
+/* Same loop with hipEvents around every step-kernel launch; returns summed milliseconds of the
+ * step kernel and of the reset kernel (synchronises the stream at the end; profiling only). */
+int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *actions_scratch,
+                     void *stream, double *step_ms_sum, double *reset_ms_sum, double *policy_ms_sum);
+
+const char *ge_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

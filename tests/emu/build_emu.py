@@ -1,0 +1,33 @@
+"""TEST INFRASTRUCTURE ONLY: build the CPU sanitizer harness of the HIP kernels (see hip_emu.h)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "graphenvs_amd", "csrc")
+OUT = os.path.join(HERE, "libgraphenvs_emu.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.h"),
+                                                               os.path.join(ROOT, "include", "graphenvs.h")]
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(s) for s in srcs):
+        return OUT
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DGE_EMU", "-x", "c++", "-ffp-contract=off",
+           "-I" + HERE, "-I" + CSRC, "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+           "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
+           os.path.join(CSRC, "ge_api.hip"), "-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+def load():
+    sys.path.insert(0, ROOT)
+    from graphenvs_amd import _lib
+    return _lib.bind(ctypes.CDLL(build()))
+
+
+if __name__ == "__main__":
+    print(build(force=True))

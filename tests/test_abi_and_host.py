@@ -1,0 +1,94 @@
+"""CPU: the C-ABI library loads and exports every symbol include/graphenvs.h declares (no compute
+calls without a GPU), config validation mirrors the reference constructors, the codec round-trips."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import graphenvs_amd as ge
+from graphenvs_amd import _lib, utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "graphenvs.h")).read()
+    declared = set(re.findall(r"\b(ge_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.ge_abi_version() == 1
+
+
+def test_struct_sizes_match_header_field_counts():
+    header = open(os.path.join(ROOT, "include", "graphenvs.h")).read()
+    body = header[header.index("typedef struct {\n  /* --- observation"):header.index("} ge_buffers;")]
+    fields = re.findall(r"\*\s*([a-z_]+);", body)
+    assert fields == _lib.BUFFER_FIELDS
+
+
+def test_layout_and_validation_without_gpu():
+    lib = _lib.load()
+    lay = _lib.GeLayout()
+    cfg = _lib.GeConfig(0, 8, 64, 192, 1, -1, 0, 0, 0, 1, -1.0, 0, 8)
+    assert lib.ge_get_layout(C.byref(cfg), C.byref(lay)) == 0
+    assert (lay.F, lay.Fe, lay.A, lay.W, lay.E, lay.obs_len) == (7, 1, 64, 1, 384, 1600)  # 7n+6m
+    cfg = _lib.GeConfig(2, 8, 256, 1024, 1, -1, 8, 0, 0, 1, -1.0, 0, 8)
+    assert lib.ge_get_layout(C.byref(cfg), C.byref(lay)) == 0
+    assert (lay.F, lay.Fe, lay.A, lay.obs_len) == (7, 2, 2048, 7 * 256 + 8 * 1024)
+    cfg = _lib.GeConfig(3, 8, 10, 20, 1, 1, 0, 0, 0, 1, -1.0, 0, 8)
+    assert lib.ge_get_layout(C.byref(cfg), C.byref(lay)) == 0 and lay.obs_len == 9 * 10 + 6 * 20  # tsp quirk, SURVEY 9.3
+    # the reference's constructor asserts
+    bad = [(_lib.GeConfig(0, 8, 10, 20, 1, 1, 0, 0, 0, 1, -1.0, 0, 8), b"shortest"),
+           (_lib.GeConfig(3, 8, 10, 20, 1, -1, 0, 0, 0, 1, -1.0, 0, 8), b"1 or 2"),
+           (_lib.GeConfig(4, 8, 10, 20, 1, 1, 0, 0, 0, 1, -1.0, 0, 8), b"Weighted"),
+           (_lib.GeConfig(0, 8, 10, 5, 1, -1, 0, 0, 0, 1, -1.0, 0, 8), b"connected")]
+    for cfg, msg in bad:
+        assert lib.ge_get_layout(C.byref(cfg), C.byref(lay)) == -1
+        assert msg.lower() in lib.ge_last_error().lower()
+
+
+def test_host_asserts_match_reference_constructors():
+    with pytest.raises(AssertionError, match="Parenting is not available"):
+        ge.vector_env.normalize_kwargs("ShortestPath-v0", 10, 20, parenting=1)
+    with pytest.raises(AssertionError, match="either 1 or 2"):
+        ge.vector_env.normalize_kwargs("TSP-v0", 10, 20)
+    with pytest.raises(AssertionError, match="Weighted graphs"):
+        ge.vector_env.normalize_kwargs("DensestSubgraph-v0", 10, 20, parenting=1, weighted=True)
+    kw = ge.vector_env.normalize_kwargs("DensestSubgraph-v0", 10, -1, parenting=1)
+    assert kw["n_edges"] == int((10 * 9 // 2) * 0.30) and kw["n_choices"] == 3.0
+
+
+def test_product_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="GPU"):
+        ge.make("ShortestPath-v0", n_nodes=10, n_edges=20)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ge.make("ShortestPath-v0", n_nodes=10, n_edges=20, device="cpu")
+
+
+def test_codec_roundtrip_and_env_info():
+    assert utils.get_env_info("ShortestPath-v0") == (7, 1, "node")
+    assert utils.get_env_info("SteinerTree-v0") == (7, 2, "edge")
+    assert utils.get_env_info("TSP-v0") == (9, 1, "node")
+    assert utils.get_env_info("DensestSubgraph-v0") == (6, 1, "node")
+    rng = np.random.default_rng(0)
+    n, m, bs = 6, 8, 3
+    nodes = rng.random((bs, n, 7), dtype=np.float32)
+    edges = rng.random((bs, 2 * m, 1), dtype=np.float32)
+    links = rng.integers(0, n, (bs, 2 * m, 2))
+    from types import SimpleNamespace
+    vec = np.stack([utils.vectorize_graph(SimpleNamespace(nodes=nodes[i], edges=edges[i], edge_links=links[i])) for i in range(bs)])
+    x, ef, ei = utils.devectorize_graph(torch.from_numpy(vec), "ShortestPath-v0", n_nodes=n, n_edges=m)
+    assert torch.equal(x, torch.from_numpy(nodes)) and torch.equal(ef, torch.from_numpy(edges))
+    assert torch.equal(ei, torch.from_numpy(links))
+    g = utils.to_pyg_graph(x, ef, ei)
+    assert g.x.shape == (bs * n, 7) and g.edge_index.shape == (2, bs * 2 * m)
+    assert torch.equal(g.edge_index[:, 2 * m:4 * m], torch.from_numpy(links[1]).T + n)  # utils.py:27 offset by i*n
+    assert torch.equal(g.ptr, torch.arange(bs + 1) * n)

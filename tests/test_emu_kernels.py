@@ -1,0 +1,63 @@
+"""CPU: the HIP kernel sources compiled for the sanitizer harness (tests/emu, UBSan + divergent-barrier
+detector) replay the reference's golden vectors.  This is a debugging aid for a GPU-less container;
+the parity claims rest on tests/test_gpu_parity.py, which runs libgraphenvs_hip.so on the MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import build_emu  # noqa: E402
+
+import graphenvs_amd as ge  # noqa: E402
+
+FAST = ["sp_n10_m20_eval", "sp_n5_m7", "sp_n33_m70", "sp_n64_m192_eval", "lp_n10_m20_p0", "lp_n10_m20_p1",
+        "st_n10_m20_d1_eval", "st_n10_m20_d3_eval", "st_n10_m20_d9_eval", "st_n5_m10_d4", "tsp_n8_m28_p1",
+        "tsp_n10_m20_p1", "tsp_n12_m30_p1_unweighted", "mis_n6_m8", "mis_n5_m7_unweighted", "ds_n10_m20_p1",
+        "ds_n10_m20_p0_eval", "ds_n100_m300_p1", "sp_n10_m20_unweighted", "st_n10_m20_d3_unweighted"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return build_emu.load()
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_emulated_kernels_replay_golden(emu, name):
+    case = gu.load_case(name)
+    st = gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=emu, **kw))
+    assert st["resets"] > 0
+
+
+def test_emulated_batch_autoreset_matches_oracle(emu):
+    import oracle
+    B, K, stride = 6, 40, 1000
+    env = ge.VectorGraphEnv("ShortestPath-v0", B, 10, 20, device="cpu", _library=emu, is_eval_env=True,
+                            seed_stride=stride, env_index_base=3)
+    env.reset(seed=5)
+    refs = [oracle.OracleEnv("ShortestPath-v0", n_nodes=10, n_edges=20, is_eval_env=True) for _ in range(B)]
+    eps = [0] * B
+    for i, r in enumerate(refs):
+        r.reset(seed=5 + 3 + i)
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=9).clone().numpy()
+        want_a = [oracle.policy_pick(r.mask(), 9, 3 + i, k) for i, r in enumerate(refs)]
+        assert a.tolist() == want_a
+        _, rew, term, _, info = env.step(a)
+        for i, r in enumerate(refs):
+            _, rr, dd, _, inf = r.step(int(a[i]))
+            assert float(rew[i]) == rr and bool(term[i]) == dd
+            if dd:
+                assert float(info["solution_cost"][i]) == inf["solution_cost"]
+                assert float(info["heuristic_solution"][i]) == inf["heuristic_solution"]
+                assert int(info["solved"][i]) == int(inf["solved"])
+                eps[i] += 1
+                r.reset(seed=(5 + 3 + i + eps[i] * stride) % 2**32)
+            assert np.array_equal(info["mask"][i].numpy(), r.mask())
+        flat = env.flat_obs().numpy()
+        for i, r in enumerate(refs):
+            assert np.array_equal(flat[i], r.obs())
+    assert sum(eps) > B

@@ -1,0 +1,213 @@
+"""GPU (MI355X): libgraphenvs_hip.so through the C ABI against (1) the golden vectors captured from the
+reference and (2) the CPU oracle on seeded batches, plus size-independent properties at the full
+BASELINE batch sizes.  Bit-exact for masks/done/indices/obs; rewards compared exactly (f64)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _ge():
+    import graphenvs_amd as ge
+    return ge
+
+
+UNBUILT = ("is not built yet",)
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_hip_engine_replays_reference_golden(name):
+    ge = _ge()
+    case = gu.load_case(name)
+    try:
+        st = gu.replay_case(case, lambda env_id, **kw: ge.make(env_id, **kw))
+    except RuntimeError as e:
+        if any(u in str(e) for u in UNBUILT):
+            pytest.skip(str(e))
+        raise
+    assert st["resets"] > 0
+
+
+CASES = [
+    ("ShortestPath-v0", dict(n_nodes=64, n_edges=192, is_eval_env=True), 256, 60),
+    ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, weighted=False), 64, 30),
+    ("LongestPath-v0", dict(n_nodes=20, n_edges=50, parenting=1, is_eval_env=True), 64, 40),
+    ("SteinerTree-v0", dict(n_nodes=40, n_edges=100, n_dests=5), 64, 80),
+    ("SteinerTree-v0", dict(n_nodes=30, n_edges=80, n_dests=29, is_eval_env=True), 32, 60),
+    ("TSP-v0", dict(n_nodes=16, n_edges=120, parenting=1), 32, 40),
+    ("TSP-v0", dict(n_nodes=20, n_edges=60, parenting=1), 32, 50),
+    ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 64, 60),
+    ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=60, parenting=0, is_eval_env=True), 64, 40),
+    ("MaxIndependentSet-v0", dict(n_nodes=70, n_edges=200), 64, 150),
+]
+
+
+@pytest.mark.parametrize("env_id,kw,B,K", CASES)
+def test_batched_autoreset_rollout_matches_oracle(env_id, kw, B, K):
+    """B slots, K vector steps with the device policy and same-step autoreset; every slot is replayed on
+    the CPU oracle with reset(seed=(s0 + k*stride) mod 2^32) per episode."""
+    import oracle
+    ge = _ge()
+    stride, base, s0 = 7919, 11, 2**32 - 40  # seeds wrap around 2^32 inside the batch
+    env = ge.make_vec(env_id, B, obs_mode="flat", seed_stride=stride, env_index_base=base, **kw)
+    obs, info = env.reset(seed=s0)
+    refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+    seeds = [(s0 + base + i) % 2**32 for i in range(B)]
+    want = np.stack([r.reset(seed=s)[0] for r, s in zip(refs, seeds)])
+    assert np.array_equal(obs.cpu().numpy(), want)
+    assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs]))
+    tcount = [0] * B
+    episodes = 0
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=77).clone().cpu().numpy()
+        assert a.tolist() == [oracle.policy_pick(r.mask(), 77, base + i, tcount[i]) for i, r in enumerate(refs)]
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a).cuda())
+        rew, term = rew.cpu().numpy(), term.cpu().numpy()
+        solved, fc, fh = info["solved"].cpu().numpy(), info["solution_cost"].cpu().numpy(), info["heuristic_solution"].cpu().numpy()
+        assert not trunc.any() and not info["invalid_action"].any()
+        for i, r in enumerate(refs):
+            _, rr, dd, _, inf = r.step(int(a[i]))
+            tcount[i] += 1
+            assert rr == rew[i], (k, i, rr, rew[i])
+            assert dd == bool(term[i]), (k, i)
+            assert int(solved[i]) == (int(inf["solved"]) if "solved" in inf else -1), (k, i)
+            if dd:
+                assert fc[i] == inf["solution_cost"], (k, i)
+                if not np.isnan(inf["heuristic_solution"]):
+                    assert fh[i] == inf["heuristic_solution"], (k, i)
+                episodes += 1
+                seeds[i] = (seeds[i] + stride) % 2**32
+                r.reset(seed=seeds[i])
+        assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), k
+        if k % 10 == 9 or k == K - 1:
+            assert np.array_equal(env.flat_obs().cpu().numpy(), np.stack([r.obs() for r in refs])), k
+    assert episodes > 0
+
+
+def test_invalid_actions_are_flagged_and_leave_state_untouched():
+    ge = _ge()
+    env = ge.make_vec("ShortestPath-v0", 8, n_nodes=10, n_edges=20, autoreset=False, obs_mode="flat")
+    obs, info = env.reset(seed=3)
+    before = {k: v.clone() for k, v in env.state_dict().items() if k in ("x", "head", "node_bits", "cost", "mask", "mask_bits")}
+    mask = info["mask"].cpu().numpy()
+    bad = torch.tensor([int(np.nonzero(~mask[i])[0][0]) for i in range(8)], device="cuda")
+    bad[1] = 10; bad[2] = -5; bad[3] = -1  # out of range, negative, explicit no-op
+    obs, rew, term, trunc, info = env.step(bad)
+    inv = info["invalid_action"].cpu().numpy()
+    assert inv.tolist() == [True, True, True, False, True, True, True, True]
+    assert not term.any() and (rew == 0).all()
+    after = env.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), k
+    env2 = ge.make_vec("ShortestPath-v0", 8, n_nodes=10, n_edges=20, autoreset=False, strict=True)
+    env2.reset(seed=3)
+    with pytest.raises(AssertionError):
+        env2.step(bad)
+
+
+def test_autoreset_off_freezes_finished_slots():
+    ge = _ge()
+    env = ge.make_vec("MaxIndependentSet-v0", 4, n_nodes=6, n_edges=8, autoreset=False)
+    env.reset(seed=0)
+    for k in range(6):
+        obs, rew, term, trunc, info = env.step(torch.full((4,), k, device="cuda"))
+    assert term.all() and (env.t["status"] == 1).all()
+    x = env.t["x"].clone()
+    obs, rew, term, trunc, info = env.step(torch.zeros(4, dtype=torch.int64, device="cuda"))
+    assert not term.any() and (rew == 0).all() and torch.equal(x, env.t["x"])
+
+
+def test_shards_are_invariant_to_the_partition():
+    """the RNG is keyed by the global slot index, so a 2-way shard equals the unsharded batch."""
+    ge = _ge()
+    kw = dict(n_nodes=24, n_edges=60, obs_mode="flat")
+    whole = ge.make_vec("ShortestPath-v0", 64, seed_stride=64, **kw)
+    lo = ge.make_vec("ShortestPath-v0", 32, seed_stride=64, env_index_base=0, **kw)
+    hi = ge.make_vec("ShortestPath-v0", 32, seed_stride=64, env_index_base=32, **kw)
+    for e in (whole, lo, hi):
+        e.reset(seed=123)
+    for k in range(40):
+        for e in (whole, lo, hi):
+            e.step(e.sample_random_actions(policy_seed=5))
+        assert torch.equal(whole.t["reward"], torch.cat([lo.t["reward"], hi.t["reward"]]))
+        assert torch.equal(whole.t["terminated"], torch.cat([lo.t["terminated"], hi.t["terminated"]]))
+    assert torch.equal(whole.flat_obs(), torch.cat([lo.flat_obs(), hi.flat_obs()]))
+    assert torch.equal(whole.t["episode"], torch.cat([lo.t["episode"], hi.t["episode"]]))
+
+
+def test_pyg_view_matches_flat_codec():
+    ge = _ge()
+    from graphenvs_amd import utils
+    B, n, m = 16, 12, 30
+    env = ge.make_vec("SteinerTree-v0", B, n_nodes=n, n_edges=m, n_dests=3)
+    g, info = env.reset(seed=1)
+    flat = env.flat_obs()
+    x, ef, ei = utils.devectorize_graph(flat, "SteinerTree-v0", n_nodes=n, n_edges=m)
+    pg = utils.to_pyg_graph(x, ef, ei)
+    assert torch.equal(pg.x, g.x) and torch.equal(pg.edge_attr, g.edge_attr) and torch.equal(pg.edge_index, g.edge_index)
+    assert torch.equal(pg.batch, g.batch) and torch.equal(pg.ptr, g.ptr)
+    assert torch.equal(env.edge_links(), ei)
+
+
+@pytest.mark.parametrize("env_id,kw,B,K", [
+    ("ShortestPath-v0", dict(n_nodes=64, n_edges=192), 65536, 60),     # BASELINE config 2
+    ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), 2048, 130),  # config 3 shape, reduced batch
+    ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 2048, 40),  # config 4 shape, one shard slice
+])
+def test_full_size_invariants_and_sampled_oracle_parity(env_id, kw, B, K):
+    """At BASELINE sizes: size-independent invariants on every slot + exact oracle replay of sampled slots."""
+    import oracle
+    ge = _ge()
+    env = ge.make_vec(env_id, B, **kw)
+    env.reset(seed=0)
+    sample = sorted(set(np.random.default_rng(0).integers(0, B, 6).tolist() + [0, B - 1]))
+    refs = {i: oracle.OracleEnv(env_id, **kw) for i in sample}
+    seeds = {i: i for i in sample}
+    for i in sample:
+        refs[i].reset(seed=i)
+    total_done = 0
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=3)
+        a_cpu = a[sample].cpu().numpy() if len(sample) else None
+        obs, rew, term, trunc, info = env.step(a)
+        total_done += int(term.sum())
+        rs, ts = rew[sample].cpu().numpy(), term[sample].cpu().numpy()
+        ms = info["mask"][sample].cpu().numpy()
+        for j, i in enumerate(sample):
+            _, rr, dd, _, _ = refs[i].step(int(a_cpu[j]))
+            assert rr == rs[j] and dd == bool(ts[j]), (k, i)
+            if dd:
+                seeds[i] = (seeds[i] + B) % 2**32
+                refs[i].reset(seed=seeds[i])
+            assert np.array_equal(ms[j], refs[i].mask()), (k, i)
+        assert not info["invalid_action"].any()
+    t = env.t
+    assert int(t["tstep"].sum()) == B * K and int(t["episode"].sum()) == total_done
+    # mask bytes == packed bits on every slot
+    bits = t["mask_bits"].cpu().numpy().view(np.uint64)
+    unpacked = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :env.A].astype(bool)
+    assert np.array_equal(unpacked, t["mask"].cpu().numpy().astype(bool))
+    if env_id == "ShortestPath-v0":
+        # mask == N(head) & ~visited; visited flags in x mirror node_bits; exactly one target per slot
+        n = env.n
+        head = t["head"].long()
+        adj = t["adj_bits"].view(B, n)[torch.arange(B, device="cuda"), head]
+        assert torch.equal(t["mask_bits"][:, 0], adj & ~t["node_bits"][:, 0])
+        x = t["x"].view(B, n, env.F)
+        vis = torch.zeros(B, dtype=torch.int64, device="cuda")
+        for v in range(n):
+            vis |= (x[:, v, 0] == 1).long() << v
+        assert torch.equal(vis, t["node_bits"][:, 0])
+        assert (x[:, :, 1].sum(1) == 1).all()
+        # edge_index is symmetric and row-major by source inside every slot
+        ei = t["edge_index"].view(2, B, env.E)
+        assert (ei[0, :, 1:] >= ei[0, :, :-1]).all()
+    g = env.graph()
+    assert g.x.shape == (B * env.n, env.F) and g.edge_index.shape == (2, B * env.E)
+    for i in sample:
+        flat_i = torch.cat([t["x"].view(B, -1)[i], t["edge_attr"].view(B, -1)[i],
+                            (t["edge_index"].view(2, B, env.E)[:, i].T - i * env.n).reshape(-1).float()]).cpu().numpy()
+        assert np.array_equal(flat_i, refs[i].obs()), i
