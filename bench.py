@@ -97,8 +97,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle  # test infrastructure, used here only as the reported CPU baseline
         cores = os.cpu_count() or 1
-        cpu_envs = args.cpu_envs or 32 * cores
-        cpu_steps = 100
+        cpu_envs = args.cpu_envs or 64 * cores
+        cpu_steps = 1000
         oracle.rollout("ShortestPath-v0", n_envs=cores, n_steps=10, n_nodes=n, n_edges=m, n_threads=cores)
         t1 = time.perf_counter()
         r = oracle.rollout("ShortestPath-v0", n_envs=cpu_envs, n_steps=cpu_steps, n_nodes=n, n_edges=m,

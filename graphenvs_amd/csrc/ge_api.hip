@@ -229,3 +229,10 @@ extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_st
   if (policy_ms) *policy_ms = tp;
   return GE_OK;
 }
+
+#if defined(GE_STAMPS) && !defined(GE_EMU)
+// diagnostic build only: copy out the phase timestamps of slot 0 (synchronises)
+extern "C" int ge_debug_read_stamps(unsigned long long *out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(ge_stamp_buf), 32 * sizeof(unsigned long long)) == hipSuccess ? GE_OK : GE_E_LAUNCH;
+}
+#endif

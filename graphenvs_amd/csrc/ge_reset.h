@@ -182,6 +182,14 @@ GE_DEV void ge_set_code(const GeRctx &c, int u, int v, int code) {
 
 enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
 
+// Diagnostic build only (-DGE_STAMPS, never shipped): 100 MHz timestamps of slot 0's reset phases.
+#if defined(GE_STAMPS) && !defined(GE_EMU)
+__device__ unsigned long long ge_stamp_buf[32];
+#define GE_STAMP(k) do { if (lane == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
+#else
+#define GE_STAMP(k) do { } while (0)
+#endif
+
 struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; };
 
 GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
@@ -192,10 +200,12 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   int src = 0, dest = -1;
 
+  GE_STAMP(0);
   if (mode != GE_RESET_INJECT) {
     // ---------------------------------------------------------------- topology (python stream)
     if (lane == 0) ge_mt_seed_python(c.mt, seed);
     ge_sync();
+    GE_STAMP(1);
     int pypos = GE_MT_N;
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
     for (;;) {
@@ -259,6 +269,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     ge_sync();
   }
 
+  GE_STAMP(2);
   // ------------------------------------------------------------------ CSR in insertion order
   if (mode != GE_RESET_INJECT) {
     for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
@@ -313,11 +324,13 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     ge_sync();
   }
 
+  GE_STAMP(3);
   // ------------------------------------------------------------------ weights + terminals (numpy stream)
   if (mode != GE_RESET_INJECT) {
     const bool needs_np = (t != GE_DENSEST_SUBGRAPH);
     int nppos = GE_MT_N;
     if (needs_np) { if (lane == 0) ge_mt_seed_numpy(c.mt, seed); ge_sync(); }
+    GE_STAMP(4);
     int64_t total = 0;  // masked-rejection draws of randint(3, 10)
     if (P.weighted) {
       if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) total = (int64_t)n * n;
@@ -369,6 +382,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       }
       ge_sync();
     }
+    GE_STAMP(5);
     // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane
     int kterm = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) ? 2 : (t == GE_STEINER_TREE ? P.n_dests + 1 : 0);
     if (kterm) {
@@ -401,6 +415,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
   if (t == GE_TSP) { src = 0; dest = -1; }
 
+  GE_STAMP(6);
   // ------------------------------------------------------------------ baselines (is_eval_env)
   double heuristic = 0.0;
   if (mode != GE_RESET_INJECT && P.is_eval) {
@@ -462,6 +477,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     else heuristic = kNaN;                                              // Kou / Christofides not built
   }
 
+  GE_STAMP(7);
   // ------------------------------------------------------------------ structural features
   if (mode != GE_RESET_INJECT) {
     // rows sorted by column (scipy canonical CSR) for pagerank
@@ -516,6 +532,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       }
       ge_sync();
     }
+    GE_STAMP(8);
     if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
     // clustering (directed formula on the symmetric graph) -> coeff[]
     for (int i = lane; i < n; i += GE_WAVE) {
@@ -524,6 +541,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       int64_t t8 = 8 * common, dt = 2 * dg, db = dg;
       c.coeff[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
     }
+    GE_STAMP(9);
     // pagerank ([nx] _pagerank_scipy): pull over in-neighbours in ascending order
     const bool prw = (t == GE_TSP);
     const double pinit = 1.0 / (double)n;
@@ -564,6 +582,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     }
   }
 
+  GE_STAMP(10);
   // ------------------------------------------------------------------ write the slot to HBM
   const ge_buffers &G = P.buf;
   const int64_t Ne = (int64_t)P.B * E;
@@ -636,6 +655,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
   }
   ge_sync();
+  GE_STAMP(11);
 }
 
 GE_KERNEL ge_k_reset(GeParams P, const uint32_t *seeds, int mode, int counter_slot, GeInject inj) {
