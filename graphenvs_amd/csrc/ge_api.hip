@@ -9,14 +9,15 @@
 #include "ge_params.h"
 #include "ge_platform.h"
 #include "ge_reset.h"
+#include "ge_features.h"
 #include "ge_step.h"
 
 struct ge_engine {
   GeParams P;
   ge_config cfg;
-  int phase;          // which reset counter the next step kernel appends to
   int reset_grid;     // workgroups of the queue-mode reset launch
   int lds_bytes;
+  int feat_lds, feat_grid, feat_fast, gen_grid;  // structural-feature kernel launch geometry
   hipEvent_t ev[4];
   bool have_events;
 };
@@ -67,8 +68,10 @@ static int derive(const ge_config *cfg, GeParams &P) {
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
+  if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
   ge_make_lds(P);
-  if (P.lds.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
+  ge_make_ldsf(P);
+  if (P.lds.total > kMaxLds || P.ldsf.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
   return GE_OK;
 }
 
@@ -89,17 +92,17 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   GeParams P;
   int rc = derive(cfg, P);
   if (rc != GE_OK) return rc;
-  const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->adj_bits, bufs->head,
+  const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->scode, bufs->adj_bits, bufs->head,
                         bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->cost, bufs->counters, bufs->seed,
                         bufs->episode, bufs->tstep, bufs->status, bufs->heuristic, bufs->mask, bufs->mask_bits, bufs->reward,
                         bufs->terminated, bufs->invalid, bufs->solved, bufs->final_cost, bufs->final_heur, bufs->final_len,
-                        bufs->reset_list, bufs->reset_count};
+                        bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
   P.buf = *bufs;
   ge_engine *e = new (std::nothrow) ge_engine();
   if (!e) return fail(GE_E_BADARG, "out of host memory");
-  e->P = P; e->cfg = *cfg; e->phase = 0; e->lds_bytes = P.lds.total; e->have_events = false;
+  e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false;
   int per_cu = kMaxLds / (P.lds.total > 0 ? P.lds.total : 1);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
@@ -109,13 +112,27 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
     hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset, P.lds.total);
     if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
+  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  e->feat_fast = (P.n <= 64) ? 1 : 0;
+  e->feat_lds = e->feat_fast ? ge_f64_bytes(P.E, P.env_type == GE_TSP, nblk) : P.ldsf.total;
+  if (e->feat_lds > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "feature kernel does not fit LDS"); }
+  if (P.ldsf.total > 64 * 1024) {
+    hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features, P.ldsf.total);
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the feature kernel"); }
+  }
+  if (e->feat_fast && e->feat_lds > 64 * 1024) {
+    hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features64, e->feat_lds);
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the n<=64 feature kernel"); }
+  }
+  { int per = kMaxLds / P.ldsf.total; if (per > 16) per = 16; if (per < 1) per = 1; e->gen_grid = 256 * per; if (e->gen_grid > P.B) e->gen_grid = P.B; }
+  { int per = kMaxLds / e->feat_lds; if (per > 16) per = 16; if (per < 1) per = 1; e->feat_grid = 256 * per; if (e->feat_grid > P.B) e->feat_grid = P.B; }
   *out = e;
   return GE_OK;
 }
 
 extern "C" int ge_destroy(ge_engine *e) {
   if (!e) return GE_OK;
-  if (e->have_events) for (int k = 0; k < 4; k++) hipEventDestroy(e->ev[k]);
+  if (e->have_events) for (int k = 0; k < 4; k++) (void)hipEventDestroy(e->ev[k]);
   delete e;
   return GE_OK;
 }
@@ -126,18 +143,29 @@ static int check_launch(const char *what) {
   return GE_OK;
 }
 
-static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, int slot, const GeInject &inj, void *stream) {
+static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, void *stream) {
   int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  GE_LAUNCH(ge_k_reset, grid, GE_WAVE, e->lds_bytes, stream, e->P, seeds, mode, slot, inj);
-  return check_launch("reset kernel");
+  GE_LAUNCH(ge_k_reset, grid, GE_WAVE, e->lds_bytes, stream, e->P, seeds, mode, inj);
+  int rc = check_launch("reset kernel");
+  if (rc != GE_OK || mode == GE_RESET_INJECT) return rc;
+  int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);
+  if (e->feat_fast) {
+    GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode);
+    rc = check_launch("feature kernel (n <= 64)");
+    if (rc != GE_OK) return rc;
+    int g2 = e->gen_grid < 64 ? e->gen_grid : 64;  // normally an empty list
+    GE_LAUNCH(ge_k_features, g2, GE_WAVE, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
+    return check_launch("feature kernel (fallback list)");
+  }
+  GE_LAUNCH(ge_k_features, fgrid, GE_WAVE, e->feat_lds, stream, e->P, mode);
+  return check_launch("feature kernel");
 }
 
 extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
   if (!e || !seeds) return fail(GE_E_BADARG, "null argument");
-  if (hipMemsetAsync(e->P.buf.reset_count, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "memset failed");
-  e->phase = 0;
+ 
   GeInject none = {nullptr, nullptr, nullptr, nullptr};
-  return launch_reset(e, seeds, GE_RESET_ALL, 0, none, stream);
+  return launch_reset(e, seeds, GE_RESET_ALL, none, stream);
 }
 
 extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
@@ -145,19 +173,36 @@ extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t
   if (!e || !links || !wcode || !x) return fail(GE_E_BADARG, "null argument");
   const int t = e->P.env_type;
   if ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) && !terminals) return fail(GE_E_BADARG, "terminals required");
-  if (hipMemsetAsync(e->P.buf.reset_count, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "memset failed");
-  e->phase = 0;
+ 
   GeInject inj = {links, wcode, x, terminals};
-  return launch_reset(e, nullptr, GE_RESET_INJECT, 0, inj, stream);
+  return launch_reset(e, nullptr, GE_RESET_INJECT, inj, stream);
 }
 
-static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P.W * 8 + GE_STEP_BLOCK; }
+static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P.W * 8 + GE_STEP_BLOCK + 64; }
+
+extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream);
+
+static bool path64(const ge_engine *e) {
+  return (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1;
+}
 
 extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {
   if (!e || !actions) return fail(GE_E_BADARG, "null argument");
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  GE_LAUNCH(ge_k_step, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, e->phase);
+  if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0);
+  else GE_LAUNCH(ge_k_step, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions);
   return check_launch("step kernel");
+}
+
+// sample + step in one launch where the fused kernel exists, else two launches; `scratch` receives the actions
+static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch, void *stream) {
+  if (path64(e)) {
+    int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+    GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, scratch, policy_seed);
+    return check_launch("fused sample+step kernel");
+  }
+  int rc = ge_sample_actions(e, policy_seed, scratch, stream);
+  return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
 }
 
 extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
@@ -165,9 +210,8 @@ extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
   int rc = GE_OK;
   if (e->P.autoreset) {
     GeInject none = {nullptr, nullptr, nullptr, nullptr};
-    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, e->phase, none, stream);
+    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, none, stream);
   }
-  e->phase ^= 1;
   return rc;
 }
 
@@ -197,8 +241,8 @@ extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *ac
 extern "C" int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *scratch, void *stream) {
   if (!e || !scratch) return fail(GE_E_BADARG, "null argument");
   for (int s = 0; s < n_steps; s++) {
-    int rc = ge_sample_actions(e, policy_seed, scratch, stream);
-    if (rc == GE_OK) rc = ge_step(e, scratch, stream);
+    int rc = sample_and_step(e, policy_seed, scratch, stream);
+    if (rc == GE_OK) rc = ge_reset_pending(e, stream);
     if (rc != GE_OK) return rc;
   }
   return GE_OK;
@@ -211,17 +255,18 @@ extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_st
   double ts = 0, tr = 0, tp = 0;
   hipStream_t st = (hipStream_t)stream;
   for (int s = 0; s < n_steps; s++) {
-    hipEventRecord(e->ev[0], st);
-    int rc = ge_sample_actions(e, policy_seed, scratch, stream);
-    hipEventRecord(e->ev[1], st);
-    if (rc == GE_OK) rc = ge_step_only(e, scratch, stream);
-    hipEventRecord(e->ev[2], st);
+    int rc = GE_OK;
+    (void)hipEventRecord(e->ev[0], st);
+    if (!path64(e)) rc = ge_sample_actions(e, policy_seed, scratch, stream);
+    (void)hipEventRecord(e->ev[1], st);
+    if (rc == GE_OK) rc = path64(e) ? sample_and_step(e, policy_seed, scratch, stream) : ge_step_only(e, scratch, stream);
+    (void)hipEventRecord(e->ev[2], st);
     if (rc == GE_OK) rc = ge_reset_pending(e, stream);
-    hipEventRecord(e->ev[3], st);
+    (void)hipEventRecord(e->ev[3], st);
     if (rc != GE_OK) return rc;
     if (hipEventSynchronize(e->ev[3]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventSynchronize failed");
     float a = 0, b = 0, c = 0;
-    hipEventElapsedTime(&a, e->ev[0], e->ev[1]); hipEventElapsedTime(&b, e->ev[1], e->ev[2]); hipEventElapsedTime(&c, e->ev[2], e->ev[3]);
+    (void)hipEventElapsedTime(&a, e->ev[0], e->ev[1]); (void)hipEventElapsedTime(&b, e->ev[1], e->ev[2]); (void)hipEventElapsedTime(&c, e->ev[2], e->ev[3]);
     tp += a; ts += b; tr += c;
   }
   if (step_ms) *step_ms = ts;

@@ -1,0 +1,368 @@
+// Structural-feature kernels: the five columns of feature_extraction.py:6-37 for freshly generated slots.
+//   ge_features_generic_env : any n; graph staged in LDS, level-synchronous Brandes, one source at a time.
+//   ge_features64_env       : n <= 64; one LANE per BFS source -- every lane walks its own shortest-path DAG
+//                             with 64-bit set arithmetic (ctz over frontier words), sigma/delta live in LDS
+//                             columns [node][lane], so the 64 sources advance together without barriers.
+// Both produce float64 results in the reference's operation order where the order is observable, then round to
+// float32 exactly once (sf = torch.tensor(sf)).
+#pragma once
+#include "ge_params.h"
+#include "ge_platform.h"
+#include "ge_reset.h"
+
+struct GeFctx {
+  uint64_t *abits; int *rowptr; uint16_t *colw; uint16_t *scw; int *dist;
+  double *sigma, *delta, *coeff, *bc, *prx, *prn, *sinv, *diff, *clos;
+};
+
+GE_DEV GeFctx ge_carve_f(const GeParams &P) {
+  unsigned char *s = ge_dyn_smem();
+  const GeLdsF &L = P.ldsf;
+  GeFctx c;
+  c.abits = (uint64_t *)(s + L.abits); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
+  c.scw = (uint16_t *)(s + L.scw); c.dist = (int *)(s + L.dist);
+  double *f = (double *)(s + L.f64a);
+  c.sigma = f; c.delta = f + P.n; c.coeff = f + 2 * P.n; c.bc = f + 3 * P.n; c.prx = f + 4 * P.n;
+  c.prn = f + 5 * P.n; c.sinv = f + 6 * P.n; c.diff = f + 7 * P.n; c.clos = f + 8 * P.n;
+  return c;
+}
+
+GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
+  const int lane = ge_tid();
+  const int n = P.n, W = P.W, E = P.E, F = P.F, t = P.env_type;
+  const ge_buffers &G = P.buf;
+  const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
+  GeFctx c = ge_carve_f(P);
+  // stage the slot's graph in LDS
+  for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = G.adj_bits[nbase * W + i];
+  for (int v = lane; v <= n; v += GE_WAVE) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
+  for (int idx = lane; idx < E; idx += GE_WAVE) c.colw[idx] = G.colw[ebase + idx];
+  ge_sync();
+  // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row
+  for (int v = lane; v < n; v += GE_WAVE)
+    for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
+      uint16_t e = c.colw[k];
+      c.scw[c.rowptr[v] + ge_rank_below(c.abits + v * W, e >> 4)] = e;
+    }
+  for (int v = lane; v < n; v += GE_WAVE) c.bc[v] = 0.0;
+  ge_sync();
+  // Brandes betweenness + closeness: one level-synchronous BFS per source
+  for (int s = 0; s < n; s++) {
+    for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
+    ge_sync();
+    int d = 0, reach = 1; int64_t tot = 0;
+    for (;;) {  // forward: discover level d+1, sigma by pull from level d
+      // a node moves from -1 to d+1, never to d, so lanes still testing dist[u] == d are unaffected
+      uint64_t any = 0; int found = 0;
+      for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+        int v = k0 + lane; bool hit = false;
+        if (v < n && c.dist[v] < 0) {
+          double sg = 0.0;
+          for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int u = c.colw[k] >> 4; if (c.dist[u] == d) { sg += c.sigma[u]; hit = true; } }
+          if (hit) { c.sigma[v] = sg; c.dist[v] = d + 1; }
+        }
+        uint64_t b = ge_ballot(hit);
+        any |= b; found += ge_popc64(b);
+      }
+      ge_sync();
+      if (!any) break;
+      d++; reach += found; tot += (int64_t)d * found;
+    }
+    for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
+      for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev) { c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bc[v] += c.delta[v]; }
+      ge_sync();
+      for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev - 1) {
+        double acc = 0.0, sv = c.sigma[v];
+        for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int w = c.colw[k] >> 4; if (c.dist[w] == lev) acc += sv * c.coeff[w]; }
+        c.delta[v] = acc;
+      }
+      ge_sync();
+    }
+    if (lane == 0) {  // closeness_centrality, wf_improved
+      double cc = 0.0;
+      if (tot > 0 && n > 1) { cc = ((double)reach - 1.0) / (double)tot; double sc = ((double)reach - 1.0) / (double)(n - 1); cc *= sc; }
+      c.clos[s] = cc;
+    }
+    ge_sync();
+  }
+  if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
+  // clustering (directed formula on the symmetric graph) -> coeff[]
+  for (int i = lane; i < n; i += GE_WAVE) {
+    int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
+    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) { int j = c.colw[k] >> 4; for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]); }
+    int64_t t8 = 8 * common, dt = 2 * dg, db = dg;
+    c.coeff[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
+  }
+  // pagerank ([nx] _pagerank_scipy): pull over in-neighbours in ascending order
+  const bool prw = (t == GE_TSP);
+  const double pinit = 1.0 / (double)n;
+  int ndang = 0;
+  for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+    int i = k0 + lane; bool dang = false;
+    if (i < n) {
+      double S = 0.0;
+      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? ge_wlut(c.scw[k] & 15) : 1.0) * 1.0;
+      c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
+      c.prx[i] = pinit;
+      dang = (c.rowptr[i + 1] == c.rowptr[i]);
+    }
+    ndang += ge_popc64(ge_ballot(dang));
+  }
+  ge_sync();
+  const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
+  bool conv = false;
+  for (int it = 0; it < 100 && !conv; it++) {
+    double dsum = 0.0;
+    if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
+    for (int i = lane; i < n; i += GE_WAVE) {
+      double acc = 0.0;
+      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
+        int j = c.scw[k] >> 4;
+        double dat = c.sinv[j] * (prw ? ge_wlut(c.scw[k] & 15) : 1.0);
+        acc += dat * c.prx[j];
+      }
+      double xn = alpha * (acc + dsum * pinit) + oma * pinit;
+      c.prn[i] = xn;
+      c.diff[i] = __builtin_fabs(xn - c.prx[i]);
+    }
+    ge_sync();
+    double err = ge_pw<5>(c.diff, n, lane);
+    for (int i = lane; i < n; i += GE_WAVE) c.prx[i] = c.prn[i];
+    ge_sync();
+    if (err < (double)n * tol) conv = true;
+  }
+
+  // sf = torch.tensor(sf) -> float32; x[:, -5:] = sf
+  for (int v = lane; v < n; v += GE_WAVE) {
+    float *xr = G.x + (nbase + v) * F + P.nflag;
+    xr[0] = (float)(2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]));
+    xr[1] = (float)c.bc[v]; xr[2] = (float)c.clos[v]; xr[3] = (float)c.prx[v]; xr[4] = (float)c.coeff[v];
+  }
+  ge_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// n <= 64 fast path.  LDS carve (bytes): abits 512 | lvl LV*512 | sig 64*66*2 | del 64*65*8 |
+// x,y,sinv,diff 4*512 | scode E (TSP only) | pre.
+#ifndef GE_F64_LV
+#define GE_F64_LV 12   // BFS levels kept per source; deeper graphs (or sigma > 65535) take the generic path
+#endif
+#define GE_F64_SS 66   // u16 stride of a sigma row  (33 dwords: odd, spreads banks)
+#define GE_F64_SD 65   // f64 stride of a delta row
+
+struct GeF64 { uint64_t *abits, *lvl; uint16_t *sig; double *del, *x, *y, *sinv, *diff; uint8_t *scode; };
+
+GE_HOSTDEV int ge_f64_bytes(int E, int tsp, int nblk) {
+  int o = 512 + GE_F64_LV * 512 + 64 * GE_F64_SS * 2 + 64 * GE_F64_SD * 8 + 4 * 512;
+  o = (o + 15) & ~15;
+  if (tsp) o += (E + 15) & ~15;
+  return o + (nblk + 2) * 4 + 16;
+}
+
+GE_DEV GeF64 ge_carve_f64(int E, int tsp) {
+  unsigned char *s = ge_dyn_smem();
+  GeF64 c;
+  c.abits = (uint64_t *)s; s += 512;
+  c.lvl = (uint64_t *)s; s += GE_F64_LV * 512;
+  c.del = (double *)s; s += 64 * GE_F64_SD * 8;
+  c.x = (double *)s; s += 512; c.y = (double *)s; s += 512; c.sinv = (double *)s; s += 512; c.diff = (double *)s; s += 512;
+  c.sig = (uint16_t *)s; s += 64 * GE_F64_SS * 2;
+  c.scode = (uint8_t *)(((uintptr_t)s + 15) & ~(uintptr_t)15);
+  return c;
+}
+GE_DEV int *ge_f64_pre(int E, int tsp, int nblk) { return (int *)(ge_dyn_smem() + ge_f64_bytes(E, tsp, nblk) - (nblk + 2) * 4 - 8); }
+
+// 256-thread workgroup: the Brandes walks are latency-bound chains of LDS round trips, so the 64 sources are
+// spread over four waves (16 lanes each) that run on the CU's four SIMDs; the node-per-lane phases (betweenness
+// reduction, closeness, clustering, pagerank) run on the first wave.  Slots that are too deep or whose path
+// counts exceed 16 bits are appended to work_list for the generic kernel.
+#define GE_F64_THREADS 256
+GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
+  const int tid = ge_tid();
+  const int lane = tid;  // node index in the node-per-lane phases (first wave only)
+  const int n = P.n, E = P.E, F = P.F, t = P.env_type;
+  const ge_buffers &G = P.buf;
+  const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
+  const bool prw = (t == GE_TSP);
+  GeF64 c = ge_carve_f64(E, prw);
+  const bool live = lane < n;
+  GE_STAMP(11);
+  const uint64_t adj = live ? G.adj_bits[nbase + lane] : 0ull;
+  const int deg = ge_popc64(adj);
+  if (tid < 64) c.abits[tid] = adj;
+  if (tid == 0) *ovf_flag = 0;
+  for (int i = tid; i < 64 * GE_F64_SS / 2; i += GE_F64_THREADS) ((uint32_t *)c.sig)[i] = 0u;
+  for (int i = tid; i < 64 * GE_F64_SD; i += GE_F64_THREADS) c.del[i] = 0.0;
+  if (prw) for (int i = tid; i < E; i += GE_F64_THREADS) c.scode[i] = G.scode[ebase + i];
+  ge_sync();
+
+  GE_STAMP(12);
+  // ---- Brandes, lane = source.  Forward: BFS + path counts, pushing sigma along DAG edges.
+  const int s = (tid >> 6) * 16 + (tid & 63);  // source of this thread (lanes 0..15 of each wave)
+  const bool walker = (tid & 63) < 16 && s < n;
+  bool ovf = false;
+  int D = 0, reach = 1; int64_t tot = 0;
+  if (walker) {
+    // one node per iteration in every lane (each lane visits its n reachable nodes once); the pushes of a node
+    // go out four at a time so their LDS reads overlap (the targets of one node are distinct: no RMW hazard)
+    uint64_t visited = 1ull << s, cur = visited, nxt = 0;
+    c.sig[s * GE_F64_SS + s] = 1;
+    for (;;) {
+      if (cur == 0) {
+        if (!nxt) break;
+        visited |= nxt; D++;
+        if (D < GE_F64_LV) c.lvl[D * 64 + s] = nxt; else ovf = true;
+        const int cnt = ge_popc64(nxt);
+        reach += cnt; tot += (int64_t)D * cnt;
+        cur = nxt; nxt = 0;
+      }
+      const int u = ge_ctz64(cur); cur &= cur - 1;
+      const uint32_t su = c.sig[u * GE_F64_SS + s];
+      uint64_t cand = c.abits[u] & ~visited;
+      nxt |= cand;
+      while (cand) {
+        const int v0 = ge_ctz64(cand); cand &= cand - 1;
+        const bool h1 = cand != 0; const int v1 = h1 ? ge_ctz64(cand) : v0; cand &= cand - 1;
+        const bool h2 = cand != 0; const int v2 = h2 ? ge_ctz64(cand) : v0; cand &= cand - 1;
+        const bool h3 = cand != 0; const int v3 = h3 ? ge_ctz64(cand) : v0; cand &= cand - 1;
+        const uint32_t r0 = c.sig[v0 * GE_F64_SS + s], r1 = c.sig[v1 * GE_F64_SS + s];
+        const uint32_t r2 = c.sig[v2 * GE_F64_SS + s], r3 = c.sig[v3 * GE_F64_SS + s];
+        const uint32_t n0 = r0 + su, n1 = r1 + su, n2 = r2 + su, n3 = r3 + su;
+        if ((n0 | (h1 ? n1 : 0u) | (h2 ? n2 : 0u) | (h3 ? n3 : 0u)) > 0xffffu) ovf = true;
+        c.sig[v0 * GE_F64_SS + s] = (uint16_t)n0;
+        if (h1) c.sig[v1 * GE_F64_SS + s] = (uint16_t)n1;
+        if (h2) c.sig[v2 * GE_F64_SS + s] = (uint16_t)n2;
+        if (h3) c.sig[v3 * GE_F64_SS + s] = (uint16_t)n3;
+      }
+    }
+  }
+  if (ovf) *ovf_flag = 1;
+  ge_sync();
+  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
+    if (tid == 0) { int k = atomicAdd(&G.work_count[0], 1); G.work_list[k] = env; }
+    ge_sync();
+    return;
+  }
+  GE_STAMP(13);
+  // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
+  if (walker) {
+    int d = D;
+    uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
+    uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
+    while (d >= 1) {
+      if (cur == 0) {
+        d--;
+        if (d >= 1) { cur = c.lvl[d * 64 + s]; prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s); }
+        continue;
+      }
+      const int w = ge_ctz64(cur); cur &= cur - 1;
+      const double coeff = (1.0 + c.del[w * GE_F64_SD + s]) / (double)c.sig[w * GE_F64_SS + s];
+      uint64_t pb = c.abits[w] & prev;
+      while (pb) {  // predecessors of w are distinct nodes: four independent read-modify-writes per round
+        const int v0 = ge_ctz64(pb); pb &= pb - 1;
+        const bool h1 = pb != 0; const int v1 = h1 ? ge_ctz64(pb) : v0; pb &= pb - 1;
+        const bool h2 = pb != 0; const int v2 = h2 ? ge_ctz64(pb) : v0; pb &= pb - 1;
+        const bool h3 = pb != 0; const int v3 = h3 ? ge_ctz64(pb) : v0; pb &= pb - 1;
+        const double s0 = (double)c.sig[v0 * GE_F64_SS + s], s1 = (double)c.sig[v1 * GE_F64_SS + s];
+        const double s2 = (double)c.sig[v2 * GE_F64_SS + s], s3 = (double)c.sig[v3 * GE_F64_SS + s];
+        const double d0 = c.del[v0 * GE_F64_SD + s], d1 = c.del[v1 * GE_F64_SD + s];
+        const double d2 = c.del[v2 * GE_F64_SD + s], d3 = c.del[v3 * GE_F64_SD + s];
+        c.del[v0 * GE_F64_SD + s] = d0 + s0 * coeff;
+        if (h1) c.del[v1 * GE_F64_SD + s] = d1 + s1 * coeff;
+        if (h2) c.del[v2 * GE_F64_SD + s] = d2 + s2 * coeff;
+        if (h3) c.del[v3 * GE_F64_SD + s] = d3 + s3 * coeff;
+      }
+    }
+  }
+  // closeness (wf_improved) of source s, handed to the node-per-lane phase through LDS
+  if (walker) {
+    double cl = 0.0;
+    if (tot > 0 && n > 1) { cl = ((double)reach - 1.0) / (double)tot; cl *= ((double)reach - 1.0) / (double)(n - 1); }
+    c.y[s] = cl;
+  }
+  ge_sync();
+  GE_STAMP(14);
+  if (tid < 64) {  // the remaining phases are one wave wide: wave-level LDS hand-offs only
+  // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
+  double bc = 0.0;
+  if (live) {
+    for (int src = 0; src < n; src++) if (src != lane) bc += c.del[lane * GE_F64_SD + src];
+    if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
+  }
+  const double clos = live ? c.y[lane] : 0.0;
+  // clustering (directed formula on the symmetric graph)
+  double clus = 0.0;
+  if (live) {
+    int64_t common = 0;
+    for (uint64_t r = adj; r; r &= r - 1) common += ge_popc64(adj & c.abits[ge_ctz64(r)]);
+    const int64_t t8 = 8 * common, dt = 2 * (int64_t)deg, db = deg;
+    clus = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
+  }
+  GE_STAMP(15);
+  // pagerank ([nx] _pagerank_scipy): x_new[i] = sum over in-neighbours j ascending of (sinv[j]*w_ji) * x[j]
+  int rp = 0;  // row start in ascending-neighbour order = exclusive scan of degrees
+  if (prw) { int incl = ge_wave_incl_scan(deg, lane); rp = incl - deg; }
+  double S = 0.0;
+  { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) S += (prw ? ge_wlut(c.scode[rp + k]) : 1.0) * 1.0; }
+  const double sinv = (S != 0.0) ? 1.0 / S : 0.0;
+  const double pinit = 1.0 / (double)n;
+  const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
+  const uint64_t dangling = ge_ballot(live && deg == 0);
+  double x = pinit;
+  c.sinv[lane] = sinv;
+  bool conv = false;
+  for (int it = 0; it < 100 && !conv; it++) {
+    c.x[lane] = x; c.y[lane] = sinv * x;  // unweighted: data'[j->i] * x[j] is the same product for every i
+    ge_wave_sync();
+    double dsum = 0.0;
+    { bool first = true; for (uint64_t r = dangling; r; r &= r - 1) { double xv = c.x[ge_ctz64(r)]; dsum = first ? xv : dsum + xv; first = false; } }
+    double xn = 0.0;
+    if (live) {
+      double acc = 0.0;
+      if (prw) { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) { const int j = ge_ctz64(r); acc += (c.sinv[j] * ge_wlut(c.scode[rp + k])) * c.x[j]; } }
+      else for (uint64_t r = adj; r; r &= r - 1) acc += c.y[ge_ctz64(r)];
+      xn = alpha * (acc + dsum * pinit) + oma * pinit;
+    }
+    c.diff[lane] = live ? __builtin_fabs(xn - x) : 0.0;
+    ge_wave_sync();
+    const double err = ge_pw<0>(c.diff, n, lane);
+    x = xn;
+    ge_wave_sync();
+    if (err < (double)n * tol) conv = true;
+  }
+  GE_STAMP(16);
+  if (live) {
+    float *xr = G.x + (nbase + lane) * F + P.nflag;
+    xr[0] = (float)(2.0 * (double)deg); xr[1] = (float)bc; xr[2] = (float)clos; xr[3] = (float)x; xr[4] = (float)clus;
+  }
+  }
+  ge_sync();
+  GE_STAMP(17);
+}
+
+enum { GE_FEAT_LIST = 3 };  // slots from work_list (fallback of the fast path)
+
+// mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list
+GE_KERNEL ge_k_features(GeParams P, int mode) {
+  int *pre = (int *)(ge_dyn_smem() + P.ldsf.pre);
+  const int count = (mode == GE_RESET_QUEUE) ? ge_queue_prefix(P, pre, ge_tid()) : (mode == GE_FEAT_LIST ? P.buf.work_count[0] : P.B);
+  for (int q = ge_bid(); q < count; q += ge_gdim()) {
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : (mode == GE_FEAT_LIST ? P.buf.work_list[q] : q);
+    ge_features_generic_env(P, env);
+  }
+}
+
+GE_KERNEL ge_k_features64(GeParams P, int mode) {
+  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  int *pre = ge_f64_pre(P.E, P.env_type == GE_TSP, nblk);
+  int count = P.B;
+  if (mode == GE_RESET_QUEUE) {  // the prefix scan is one wave wide
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    ge_sync();
+    count = pre[nblk];
+  }
+  for (int q = ge_bid(); q < count; q += ge_gdim()) {
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    ge_features64_env(P, env, pre + nblk + 1);
+  }
+}

@@ -17,14 +17,20 @@ struct GeLds {
   int fill;     // i32[n]    per-row fill counters / degrees
   int rowptr;   // i32[n+1]
   int colw;     // u16[E]    (col << 4) | weight code, insertion order
-  int scw;      // u16[E]    same, rows sorted by column (scipy canonical CSR)
+  int wsort;    // u8[E]     weight codes in ascending-neighbour order (the scode slab of this slot)
   int tmp;      // u32[E]    (edge id << 16 | col) scatter buffer
   int dist;     // i32[n]
   int perm;     // i32[n]
-  int f64a;     // f64[9][n] sigma, delta, coeff, bc, prx, prn, sinv, diff, clos
+  int f64a;     // f64[2][n] Dijkstra distances (sigma, delta); also stages the first mask words
   int bits;     // u64[4][W] frontier / visited / next / scratch
   int misc;     // i32[16]
+  int pre;      // i32[nblk+1] exclusive prefix of the per-workgroup reset counts
   int total;
+};
+
+// LDS carve of the generic structural-feature kernel
+struct GeLdsF {
+  int abits, rowptr, colw, scw, dist, f64a, pre, total;
 };
 
 struct GeParams {
@@ -34,6 +40,7 @@ struct GeParams {
   int64_t env_index_base, seed_stride;
   ge_buffers buf;
   GeLds lds;
+  GeLdsF ldsf;
 };
 
 static inline int ge_align16(int v) { return (v + 15) & ~15; }
@@ -48,12 +55,27 @@ static inline void ge_make_lds(GeParams &P) {
   L.fill = take(P.n * 4);
   L.rowptr = take((P.n + 1) * 4);
   L.colw = take((P.E > 0 ? P.E : 1) * 2);
-  L.scw = take((P.E > 0 ? P.E : 1) * 2);
+  L.wsort = take(P.E > 0 ? P.E : 1);
   L.tmp = take(P.complete ? 16 : (P.E > 0 ? P.E : 1) * 4);
   L.dist = take(P.n * 4);
   L.perm = take(P.n * 4);
-  L.f64a = take(9 * P.n * 8);
+  { int need = 2 * P.n * 8, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
   L.bits = take(4 * P.W * 8);
   L.misc = take(16 * 4);
+  L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
+  L.total = o;
+}
+
+static inline void ge_make_ldsf(GeParams &P) {
+  GeLdsF &L = P.ldsf;
+  int o = 0;
+  auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
+  L.abits = take(P.n * P.W * 8);
+  L.rowptr = take((P.n + 1) * 4);
+  L.colw = take((P.E > 0 ? P.E : 1) * 2);
+  L.scw = take((P.E > 0 ? P.E : 1) * 2);
+  L.dist = take(P.n * 4);
+  L.f64a = take(9 * P.n * 8);
+  L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
   L.total = o;
 }

@@ -23,6 +23,8 @@ GE_DEV unsigned char *ge_dyn_smem() {
   return ge_smem_raw;
 }
 GE_DEV void ge_sync() { __syncthreads(); }
+// LDS hand-off between lanes of ONE wave (the other waves of the workgroup do not take part)
+GE_DEV void ge_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 GE_DEV uint64_t ge_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 GE_DEV int ge_shfl_i32(int v, int src) { return __shfl(v, src, 64); }
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }

@@ -86,9 +86,9 @@ GE_DEV uint32_t ge_mask_below(uint32_t v) {  // smallest 2^k - 1 >= v
 }
 
 struct GeRctx {
-  uint32_t *mt; uint64_t *abits; uint32_t *elist; int *fill; int *rowptr; uint16_t *colw; uint16_t *scw;
+  uint32_t *mt; uint64_t *abits; uint32_t *elist; int *fill; int *rowptr; uint16_t *colw; uint8_t *wsort;
   uint32_t *tmp; int *dist; int *perm;
-  double *sigma, *delta, *coeff, *bc, *prx, *prn, *sinv, *diff, *clos;
+  double *sigma, *delta;
   uint64_t *bits; int *misc;
 };
 
@@ -98,11 +98,10 @@ GE_DEV GeRctx ge_carve(const GeParams &P) {
   GeRctx c;
   c.mt = (uint32_t *)(s + L.mt); c.abits = (uint64_t *)(s + L.abits); c.elist = (uint32_t *)(s + L.elist);
   c.fill = (int *)(s + L.fill); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
-  c.scw = (uint16_t *)(s + L.scw); c.tmp = (uint32_t *)(s + L.tmp); c.dist = (int *)(s + L.dist);
+  c.wsort = (uint8_t *)(s + L.wsort); c.tmp = (uint32_t *)(s + L.tmp); c.dist = (int *)(s + L.dist);
   c.perm = (int *)(s + L.perm);
   double *f = (double *)(s + L.f64a);
-  c.sigma = f; c.delta = f + P.n; c.coeff = f + 2 * P.n; c.bc = f + 3 * P.n; c.prx = f + 4 * P.n;
-  c.prn = f + 5 * P.n; c.sinv = f + 6 * P.n; c.diff = f + 7 * P.n; c.clos = f + 8 * P.n;
+  c.sigma = f; c.delta = f + P.n;
   c.bits = (uint64_t *)(s + L.bits); c.misc = (int *)(s + L.misc);
   return c;
 }
@@ -169,16 +168,20 @@ GE_DEV double ge_pw(const double *a, int n, int lane) {
   }
 }
 
+// number of neighbours of a bit row that are smaller than v
+GE_DEV int ge_rank_below(const uint64_t *row, int v) {
+  int r = 0;
+  for (int w = 0; w < (v >> 6); w++) r += ge_popc64(row[w]);
+  return r + ge_popc64(row[v >> 6] & ((1ull << (v & 63)) - 1ull));
+}
+
 // source node of directed edge idx
 GE_DEV int ge_row_of(const GeParams &P, const GeRctx &c, int idx) {
   return P.complete ? idx / (P.ng - 1) : (int)c.tmp[idx];
 }
 
-// write weight code for the directed entry u->v (scan of row u)
-GE_DEV void ge_set_code(const GeRctx &c, int u, int v, int code) {
-  for (int k = c.rowptr[u]; k < c.rowptr[u + 1]; k++)
-    if ((c.colw[k] >> 4) == v) { c.colw[k] = (uint16_t)((v << 4) | code); return; }
-}
+// slot of the directed entry u->v in ascending-neighbour order (no row scan: rank inside the bit row)
+GE_DEV int ge_sorted_pos(const GeRctx &c, int W, int u, int v) { return c.rowptr[u] + ge_rank_below(c.abits + u * W, v); }
 
 enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
 
@@ -219,27 +222,60 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
             if ((v >> 6) == w) bitsw &= ~(1ull << (v & 63));
             c.abits[v * W + w] = bitsw;
           }
-      } else {  // [nx] gnm_random_graph: rejection loop, one draw per iteration
-        int cnt = 0, have_u = 0, u = 0;
+      } else {
+        // [nx] gnm_random_graph, 64 draws per round.  A draw below ng is a node pick; picks pair up as (u, v) in
+        // stream order; a pair is added unless u == v or the edge exists (in the matrix, or earlier in this round).
+        int cnt = 0, have_u = 0, carry_u = 0;
+        const uint64_t below = (1ull << lane) - 1ull;
         for (;;) {
           if (pypos >= GE_MT_N) { ge_mt_twist(c.mt, lane); pypos = 0; }
-          if (lane == 0) {
-            while (cnt < m && pypos < GE_MT_N) {
-              uint32_t r = ge_temper(c.mt[pypos++]) >> shift;
-              if (r >= (uint32_t)ng) continue;
-              if (!have_u) { u = (int)r; have_u = 1; continue; }
-              int v = (int)r; have_u = 0;
-              if (u == v) continue;
-              if ((c.abits[u * W + (v >> 6)] >> (v & 63)) & 1ull) continue;
-              c.abits[u * W + (v >> 6)] |= 1ull << (v & 63);
-              c.abits[v * W + (u >> 6)] |= 1ull << (u & 63);
-              c.elist[cnt++] = (uint32_t)u | ((uint32_t)v << 16);
-            }
+          const int p = pypos + lane;
+          const bool valid = p < GE_MT_N;
+          const uint32_t r = valid ? (ge_temper(c.mt[p]) >> shift) : (uint32_t)ng;
+          const bool pick = valid && r < (uint32_t)ng;
+          const uint64_t V = ge_ballot(pick);
+          const int gidx = ge_popc64(V & below) + have_u;            // index of this pick in the u,v,u,v,... sequence
+          const bool is_v = pick && (gidx & 1);
+          const uint64_t before = V & below;
+          const int pl = before ? 63 - (int)__builtin_clzll(before) : 0;
+          const uint32_t ur = ge_shfl_u32(r, pl);
+          const int u = before ? (int)ur : carry_u, v = (int)r;
+          bool elig = is_v && u != v && !((c.abits[u * W + (v >> 6)] >> (v & 63)) & 1ull);
+          const uint32_t key = elig ? (uint32_t)((u < v ? u : v) << 12 | (u < v ? v : u)) : 0xffffffffu;
+          bool dup = false;  // the same edge proposed earlier in this round
+          for (uint64_t rem = ge_ballot(elig); rem;) {
+            const int l0 = ge_ctz64(rem);
+            const uint32_t k0 = ge_shfl_u32(key, l0);
+            const uint64_t same = ge_ballot(elig && key == k0);
+            if (elig && key == k0 && lane != l0) dup = true;
+            rem &= ~same;
           }
-          pypos = ge_shfl_i32(pypos, 0);
-          int cb = ge_shfl_i32(cnt, 0);
+          bool acc = elig && !dup;
+          uint64_t A = ge_ballot(acc);
+          int nacc = ge_popc64(A);
+          const int arank = ge_popc64(A & below);
+          const bool last_round = cnt + nacc >= m;
+          int consumed;
+          if (last_round) {  // the stream stops right after the draw that completed edge m
+            const int need = m - cnt - 1;
+            const int fl = ge_ctz64(ge_ballot(acc && arank == need));
+            acc = acc && lane <= fl;
+            consumed = fl + 1; nacc = need + 1;
+          } else {
+            consumed = (GE_MT_N - pypos < GE_WAVE) ? (GE_MT_N - pypos) : GE_WAVE;
+            const int npick = ge_popc64(V) + have_u;
+            have_u = npick & 1;
+            const uint32_t lastr = ge_shfl_u32(r, V ? 63 - (int)__builtin_clzll(V) : 0);
+            if (have_u && V) carry_u = (int)lastr;  // with no pick in this round the pending u is carried unchanged
+          }
+          if (acc) {
+            atomicOr((unsigned long long *)&c.abits[u * W + (v >> 6)], (unsigned long long)(1ull << (v & 63)));
+            atomicOr((unsigned long long *)&c.abits[v * W + (u >> 6)], (unsigned long long)(1ull << (u & 63)));
+            c.elist[cnt + arank] = (uint32_t)u | ((uint32_t)v << 16);
+          }
+          cnt += nacc; pypos += consumed;
           ge_sync();
-          if (cb >= m) break;
+          if (last_round) break;
         }
       }
       ge_sync();
@@ -331,9 +367,9 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     int nppos = GE_MT_N;
     if (needs_np) { if (lane == 0) ge_mt_seed_numpy(c.mt, seed); ge_sync(); }
     GE_STAMP(4);
-    int64_t total = 0;  // masked-rejection draws of randint(3, 10)
+    int total = 0;  // masked-rejection draws of randint(3, 10); n*n < 2^24
     if (P.weighted) {
-      if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) total = (int64_t)n * n;
+      if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) total = n * n;
       else if (t == GE_TSP) total = m;
       else if (t == GE_MAX_INDEPENDENT_SET) total = n;
     }
@@ -348,8 +384,10 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       }
       ge_sync();
     }
-    if (t == GE_MAX_INDEPENDENT_SET) { for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 10; ge_sync(); }
-    int64_t base = 0;
+    if (t == GE_MAX_INDEPENDENT_SET) { for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 10; }
+    for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
+    ge_sync();
+    int base = 0;
     while (base < total) {
       if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
       int p = nppos + lane; bool valid = p < GE_MT_N;
@@ -357,22 +395,23 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       bool acc = valid && val <= 6u;
       uint64_t bal = ge_ballot(acc);
       int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
-      int64_t idx = base + rank;
+      int idx = base + rank;
       if (acc && idx < total) {
         int code = 3 + (int)val;
-        if (t == GE_MAX_INDEPENDENT_SET) c.fill[(int)idx] = code;
+        if (t == GE_MAX_INDEPENDENT_SET) c.fill[idx] = code;
         else if (t == GE_TSP) {
-          int k = (int)c.elist[(int)idx]; int u = ge_row_of(P, c, k), v = (int)(c.colw[k] >> 4);
-          c.colw[k] = (uint16_t)((v << 4) | code);
-          ge_set_code(c, v, u, code);
+          int k = (int)c.elist[idx]; int u = ge_row_of(P, c, k), v = (int)(c.colw[k] >> 4);
+          c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, v, u)] = (uint8_t)code;
         } else {
-          int i = (int)(idx / n), j = (int)(idx % n);
-          if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) { ge_set_code(c, i, j, code); ge_set_code(c, j, i, code); }
+          int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
+          if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
+            c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
+          }
         }
       }
       int nacc = ge_popc64(bal);
       if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
-        int need = (int)(total - base - 1);
+        int need = total - base - 1;
         uint64_t lastb = ge_ballot(acc && rank == need);
         nppos += ge_ctz64(lastb) + 1;
         base = total;
@@ -382,6 +421,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       }
       ge_sync();
     }
+    for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
+      int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+      c.colw[idx] = (uint16_t)((v << 4) | c.wsort[ge_sorted_pos(c, W, u, v)]);
+    }
+    ge_sync();
     GE_STAMP(5);
     // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane
     int kterm = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) ? 2 : (t == GE_STEINER_TREE ? P.n_dests + 1 : 0);
@@ -407,6 +451,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       src = c.perm[0]; dest = c.perm[1];
     }
   } else {
+    for (int idx = lane; idx < E; idx += GE_WAVE) {
+      int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+      c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)(c.colw[idx] & 15);
+    }
+    ge_sync();
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) {
       for (int k = lane; k < T; k += GE_WAVE) c.perm[k] = inj.terminals[(int64_t)env * T + k];
       ge_sync();
@@ -477,112 +526,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     else heuristic = kNaN;                                              // Kou / Christofides not built
   }
 
-  GE_STAMP(7);
-  // ------------------------------------------------------------------ structural features
-  if (mode != GE_RESET_INJECT) {
-    // rows sorted by column (scipy canonical CSR) for pagerank
-    for (int idx = lane; idx < E; idx += GE_WAVE) c.scw[idx] = c.colw[idx];
-    ge_sync();
-    for (int v = lane; v < n; v += GE_WAVE) {
-      int lo = c.rowptr[v], hi = c.rowptr[v + 1];
-      for (int a = lo + 1; a < hi; a++) {
-        uint16_t key = c.scw[a]; int b = a - 1;
-        while (b >= lo && c.scw[b] > key) { c.scw[b + 1] = c.scw[b]; b--; }
-        c.scw[b + 1] = key;
-      }
-    }
-    for (int v = lane; v < n; v += GE_WAVE) c.bc[v] = 0.0;
-    ge_sync();
-    // Brandes betweenness + closeness: one level-synchronous BFS per source
-    for (int s = 0; s < n; s++) {
-      for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
-      ge_sync();
-      int d = 0, reach = 1; int64_t tot = 0;
-      for (;;) {  // forward: discover level d+1, sigma by pull from level d
-        // a node moves from -1 to d+1, never to d, so lanes still testing dist[u] == d are unaffected
-        uint64_t any = 0; int found = 0;
-        for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
-          int v = k0 + lane; bool hit = false;
-          if (v < n && c.dist[v] < 0) {
-            double sg = 0.0;
-            for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int u = c.colw[k] >> 4; if (c.dist[u] == d) { sg += c.sigma[u]; hit = true; } }
-            if (hit) { c.sigma[v] = sg; c.dist[v] = d + 1; }
-          }
-          uint64_t b = ge_ballot(hit);
-          any |= b; found += ge_popc64(b);
-        }
-        ge_sync();
-        if (!any) break;
-        d++; reach += found; tot += (int64_t)d * found;
-      }
-      for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
-        for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev) { c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bc[v] += c.delta[v]; }
-        ge_sync();
-        for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev - 1) {
-          double acc = 0.0, sv = c.sigma[v];
-          for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int w = c.colw[k] >> 4; if (c.dist[w] == lev) acc += sv * c.coeff[w]; }
-          c.delta[v] = acc;
-        }
-        ge_sync();
-      }
-      if (lane == 0) {  // closeness_centrality, wf_improved
-        double cc = 0.0;
-        if (tot > 0 && n > 1) { cc = ((double)reach - 1.0) / (double)tot; double sc = ((double)reach - 1.0) / (double)(n - 1); cc *= sc; }
-        c.clos[s] = cc;
-      }
-      ge_sync();
-    }
-    GE_STAMP(8);
-    if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
-    // clustering (directed formula on the symmetric graph) -> coeff[]
-    for (int i = lane; i < n; i += GE_WAVE) {
-      int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
-      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) { int j = c.colw[k] >> 4; for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]); }
-      int64_t t8 = 8 * common, dt = 2 * dg, db = dg;
-      c.coeff[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
-    }
-    GE_STAMP(9);
-    // pagerank ([nx] _pagerank_scipy): pull over in-neighbours in ascending order
-    const bool prw = (t == GE_TSP);
-    const double pinit = 1.0 / (double)n;
-    int ndang = 0;
-    for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
-      int i = k0 + lane; bool dang = false;
-      if (i < n) {
-        double S = 0.0;
-        for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? ge_wlut(c.scw[k] & 15) : 1.0) * 1.0;
-        c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
-        c.prx[i] = pinit;
-        dang = (c.rowptr[i + 1] == c.rowptr[i]);
-      }
-      ndang += ge_popc64(ge_ballot(dang));
-    }
-    ge_sync();
-    const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
-    bool conv = false;
-    for (int it = 0; it < 100 && !conv; it++) {
-      double dsum = 0.0;
-      if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
-      for (int i = lane; i < n; i += GE_WAVE) {
-        double acc = 0.0;
-        for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
-          int j = c.scw[k] >> 4;
-          double dat = c.sinv[j] * (prw ? ge_wlut(c.scw[k] & 15) : 1.0);
-          acc += dat * c.prx[j];
-        }
-        double xn = alpha * (acc + dsum * pinit) + oma * pinit;
-        c.prn[i] = xn;
-        c.diff[i] = __builtin_fabs(xn - c.prx[i]);
-      }
-      ge_sync();
-      double err = ge_pw<5>(c.diff, n, lane);
-      for (int i = lane; i < n; i += GE_WAVE) c.prx[i] = c.prn[i];
-      ge_sync();
-      if (err < (double)n * tol) conv = true;
-    }
-  }
-
-  GE_STAMP(10);
+  GE_STAMP(9);
   // ------------------------------------------------------------------ write the slot to HBM
   const ge_buffers &G = P.buf;
   const int64_t Ne = (int64_t)P.B * E;
@@ -594,22 +538,19 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     tbits[lane] = tb;
   }
   ge_sync();
-  for (int idx = lane; idx < n * F; idx += GE_WAVE) {
-    int v = idx / F, col = idx % F; float val;
-    if (mode == GE_RESET_INJECT) val = inj.x[nbase * F + idx];
-    else if (col >= P.nflag) {
-      int f = col - P.nflag;
-      double dv = f == 0 ? 2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]) : f == 1 ? c.bc[v] : f == 2 ? c.clos[v] : f == 3 ? c.prx[v] : c.coeff[v];
-      val = (float)dv;
-    } else {
-      val = 0.f;
+  if (mode == GE_RESET_INJECT) {
+    for (int idx = lane; idx < n * F; idx += GE_WAVE) G.x[nbase * F + idx] = inj.x[nbase * F + idx];
+  } else {  // flag columns only; the five structural columns are written by the features kernel
+    const int nf = P.nflag;
+    for (int idx = lane; idx < n * nf; idx += GE_WAVE) {
+      int v = idx / nf, col = idx % nf; float val = 0.f;
       bool is_t = (tbits[v >> 6] >> (v & 63)) & 1ull;
       if (t == GE_SHORTEST_PATH || t == GE_STEINER_TREE) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : 0.f);
       else if (t == GE_LONGEST_PATH) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : ((P.parenting == 0 && v == src) ? 2.f : 0.f));
       else if (t == GE_TSP) val = (col == 1 && v == 0) ? 1.f : 0.f;
       else if (t == GE_MAX_INDEPENDENT_SET) val = (col == 0) ? (float)ge_wlut(c.fill[v]) : 0.f;
+      G.x[(nbase + v) * F + col] = val;
     }
-    G.x[nbase * F + idx] = val;
   }
   for (int idx = lane; idx < E; idx += GE_WAVE) {
     int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4, code = c.colw[idx] & 15;
@@ -619,6 +560,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
     else G.edge_attr[ebase + idx] = wv;
     G.colw[ebase + idx] = c.colw[idx];
+    G.scode[ebase + idx] = c.wsort[idx];
     if (G.rev_edge) { int r = -1; for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) if ((c.colw[k] >> 4) == u) { r = k; break; } G.rev_edge[ebase + idx] = r; }
   }
   for (int v = lane; v <= n; v += GE_WAVE) G.row_ptr[(int64_t)env * (n + 1) + v] = c.rowptr[v];
@@ -655,13 +597,40 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
   }
   ge_sync();
-  GE_STAMP(11);
+  GE_STAMP(10);
 }
 
-GE_KERNEL ge_k_reset(GeParams P, const uint32_t *seeds, int mode, int counter_slot, GeInject inj) {
-  int count = (mode == GE_RESET_QUEUE) ? P.buf.reset_count[counter_slot] : P.B;
+// Queue mode: every step workgroup left (count, segment) in reset_count / reset_list; each reset workgroup
+// rebuilds the exclusive prefix of the counts in LDS and finds its slot by binary search.
+GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) {  // one wave; no barrier
+  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  int carry = 0;
+  for (int k0 = 0; k0 < nblk; k0 += GE_WAVE) {
+    int k = k0 + lane; int cnt = k < nblk ? P.buf.reset_count[k] : 0;
+    int incl = ge_wave_incl_scan(cnt, lane);
+    if (k < nblk) pre[k] = carry + incl - cnt;
+    carry += ge_shfl_i32(incl, GE_WAVE - 1);
+  }
+  if (lane == 0) pre[nblk] = carry;
+  return carry;
+}
+GE_DEV int ge_queue_prefix(const GeParams &P, int *pre, int lane) {  // 64-thread workgroups
+  int c = ge_queue_prefix_wave(P, pre, lane);
+  ge_sync();
+  return c;
+}
+GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
+  int lo = 0, hi = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid; }
+  return P.buf.reset_list[lo * GE_STEP_BLOCK + (q - pre[lo])];
+}
+
+GE_KERNEL ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj) {
+  int *pre = (int *)(ge_dyn_smem() + P.lds.pre);
+  if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
+  int count = (mode == GE_RESET_QUEUE) ? ge_queue_prefix(P, pre, ge_tid()) : P.B;
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    int env = (mode == GE_RESET_QUEUE) ? P.buf.reset_list[q] : q;
+    int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
     uint32_t seed = (mode == GE_RESET_ALL) ? seeds[env] : ((mode == GE_RESET_QUEUE) ? P.buf.seed[env] : 0u);
     ge_reset_env(P, env, seed, mode, inj);
   }

@@ -14,17 +14,28 @@ GE_DEV uint64_t ge_full_word(int A, int w) {
   return (hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull);
 }
 
-// weight code of the directed edge u -> a inside slot `env` (scan of row u; direct for complete graphs)
+// weight code of the directed edge u -> a inside slot `env`: position by rank in the bit row, no scan
 GE_DEV int ge_edge_code(const GeParams &P, int env, int u, int a) {
-  const int32_t *rp = P.buf.row_ptr + (int64_t)env * (P.n + 1);
-  const uint16_t *cw = P.buf.colw + (int64_t)env * P.E;
-  int r0 = rp[u], r1 = rp[u + 1];
-  if (P.complete) { int k = r0 + (a < u ? a : a - 1); return (k < r1 && (cw[k] >> 4) == a) ? (cw[k] & 15) : -1; }
-  for (int k = r0; k < r1; k++) { uint16_t e = cw[k]; if ((e >> 4) == a) return e & 15; }
-  return -1;
+  const uint64_t *row = P.buf.adj_bits + ((int64_t)env * P.n + u) * P.W;
+  int r0 = P.buf.row_ptr[(int64_t)env * (P.n + 1) + u];
+  return P.buf.scode[(int64_t)env * P.E + r0 + ge_rank_below(row, a)];
 }
 
-GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int counter_slot) {
+// Finished slots of this workgroup go to the workgroup's own segment of reset_list, in slot order, and the
+// segment length to reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
+GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want) {
+  const uint64_t b = ge_ballot(want);
+  const int lane = tid & 63, wave = tid >> 6, nw = ge_bdim() >> 6;
+  const int rank = ge_popc64(b & ((1ull << lane) - 1ull));
+  if (lane == 0) wcnt[wave] = ge_popc64(b);
+  ge_sync();
+  int off = 0;
+  for (int w = 0; w < wave; w++) off += wcnt[w];
+  if (want) P.buf.reset_list[i0 + off + rank] = i;
+  if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[ge_bid()] = tot; }
+}
+
+GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -34,7 +45,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int counter_slot) {
   const bool edge_mask = (t == GE_STEINER_TREE);
   bool wrote_mask = false;  // this slot's node mask changed and sits in `stage`
 
-  if (i == 0) G.reset_count[counter_slot ^ 1] = 0;  // the other counter is idle during this launch
+  bool want_reset = false;
 
   if (i < P.B) {
     const int64_t nbase = (int64_t)i * n;
@@ -201,8 +212,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int counter_slot) {
         G.final_heur[i] = G.heuristic[i];
         G.final_len[i] = len;
         if (P.autoreset) {
-          int slot = atomicAdd(&G.reset_count[counter_slot], 1);
-          G.reset_list[slot] = i;
+          want_reset = true;
           G.seed[i] = G.seed[i] + (uint32_t)P.seed_stride;
           G.episode[i] = G.episode[i] + 1;
           G.status[i] = 2;
@@ -215,11 +225,11 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int counter_slot) {
     if (wrote_mask && !edge_mask) for (int w = 0; w < W; w++) G.mask_bits[(int64_t)i * AW + w] = stage[tid * W + w];
   }
 
-  if (edge_mask) return;  // SteinerTree updates its [B, 2m] mask incrementally above
-  // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
   uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * W);
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_sync();
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
+  if (edge_mask) return;  // SteinerTree updates its [B, 2m] mask incrementally above
+  // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
   if (nb <= 0) return;
   uint8_t *out = G.mask + (int64_t)i0 * A;
@@ -251,6 +261,138 @@ GE_DEV uint64_t ge_mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+GE_DEV int ge_nth_set_bit(uint64_t word, uint32_t r) {
+  for (uint32_t k = 0; k < r; k++) word &= word - 1;
+  return ge_ctz64(word);
+}
+
+// Headline fast path: ShortestPath / LongestPath(parenting 0,1) with n <= 64.  One u64 per node set, three
+// dependent rounds of loads (slot state -> bit rows of head and action -> one weight byte), optional fused
+// sampling of the random policy (SAMPLE) so a rollout step is a single launch.
+#ifndef GE_ABL
+#define GE_ABL 0  // diagnostic ablation bits (tools/ablate_step.py); 0 in the shipped library
+#endif
+template <bool SAMPLE>
+GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actions_out, uint64_t policy_seed) {
+  const ge_buffers &G = P.buf;
+  const int tid = ge_tid();
+  const int i0 = ge_bid() * ge_bdim();
+  const int i = i0 + tid;
+  const int n = P.n, F = P.F;
+  const bool lp = (P.env_type == GE_LONGEST_PATH), open_mask = lp && P.parenting == 0;
+  uint64_t *stage = (uint64_t *)ge_dyn_smem();
+  uint8_t *flag = (uint8_t *)(stage + ge_bdim());
+  bool wrote_mask = false;
+  bool want_reset = false;
+  if (i < P.B) {
+    // round 1: slot state (coalesced)
+    const uint64_t mb = G.mask_bits[i];
+    const uint8_t st = G.status[i];
+    const int head = G.head[i];
+    const int dest = G.terminals[2 * (int64_t)i + 1];
+    double cost = G.cost[i];
+    uint64_t vis = G.node_bits[i];
+    const int64_t ts = G.tstep[i];
+    const int len0 = G.counters[2 * i + 1];
+    int64_t a64;
+    if (SAMPLE) {
+      uint32_t cnt = (uint32_t)ge_popc64(mb);
+      if (!cnt || st == 1) a64 = -1;
+      else {
+        uint64_t z = ge_mix64(policy_seed + (uint64_t)(P.env_index_base + i) * 0x9E3779B97F4A7C15ull + (uint64_t)ts * 0xD1B54A32D192ED03ull);
+        a64 = ge_nth_set_bit(mb, (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32));
+      }
+      actions_out[i] = a64;
+    } else {
+      a64 = actions_in[i];
+    }
+    const bool in_range = a64 >= 0 && a64 < (int64_t)n;
+    const int a = in_range ? (int)a64 : 0;
+    // round 2: bit rows of head and action, row start (gathers inside the slot's slab)
+    const int64_t nbase = (int64_t)i * n;
+    const uint64_t adjH = (GE_ABL & 4) ? (mb | 2) : G.adj_bits[nbase + head];
+    const uint64_t adjA = (GE_ABL & 4) ? (mb * 3) : G.adj_bits[nbase + a];
+    const int rp = (GE_ABL & 4) ? head : G.row_ptr[(int64_t)i * (n + 1) + head];
+    // round 3: weight code by rank (valid only when a is a neighbour of head)
+    const bool nbr = (adjH >> a) & 1ull;
+    int pos = rp + ge_popc64(adjH & ((1ull << a) - 1ull));
+    if (pos >= P.E) pos = P.E - 1;
+    const int code = (GE_ABL & 8) ? 3 + (pos & 3) : G.scode[(int64_t)i * P.E + pos];
+
+    double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
+    if (st == 0 && a64 != -1) {
+      const bool mbit = in_range && ((mb >> a) & 1ull);
+      const bool vis_a = (vis >> a) & 1ull;
+      if (!mbit || (lp && P.parenting >= 1 && (!nbr || vis_a))) invalid = 1;
+      else {
+        acted = true;
+        const double wgt = nbr ? ge_wlut(code) : 0.0;
+        if (lp) { reward = wgt; cost -= wgt; } else { reward = -wgt; cost -= reward; }
+        G.cost[i] = cost;
+        if (lp && (!nbr || vis_a)) { done = 1; solved = 0; reward = -2.0 * n; }  // longest_path.py:169-173
+        else {
+          if (a == dest) { done = 1; solved = 1; }
+          G.head[i] = a;
+          if (!(GE_ABL & 1)) G.x[(nbase + a) * F + 0] = 1.f;
+          vis |= 1ull << a;
+          G.node_bits[i] = vis;
+          const uint64_t nm = open_mask ? mb : (adjA & ~vis);
+          stage[tid] = nm;
+          wrote_mask = !open_mask;
+          if (!done && !nm) { done = 1; solved = 0; reward = lp ? -2.0 * n : -(double)n; }
+        }
+      }
+    }
+    G.reward[i] = reward;
+    G.terminated[i] = (uint8_t)done;
+    G.invalid[i] = (uint8_t)invalid;
+    G.solved[i] = (int8_t)solved;
+    if (acted) {
+      const int len = len0 + 1;
+      G.counters[2 * i + 1] = len;
+      G.tstep[i] = ts + 1;
+      if (done) {
+        G.final_cost[i] = cost;
+        G.final_heur[i] = G.heuristic[i];
+        G.final_len[i] = len;
+        if (P.autoreset) {
+          want_reset = true;
+          G.seed[i] = G.seed[i] + (uint32_t)P.seed_stride;
+          G.episode[i] = G.episode[i] + 1;
+          G.status[i] = 2;
+          wrote_mask = false;
+        } else {
+          G.status[i] = 1;
+        }
+      }
+    }
+    if (wrote_mask) G.mask_bits[i] = stage[tid];
+  }
+  flag[tid] = wrote_mask ? 1 : 0;
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
+  int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
+  if (nb <= 0 || (GE_ABL & 2)) return;
+  uint8_t *out = G.mask + (int64_t)i0 * n;
+  if ((n & 7) == 0) {
+    const int groups = nb * (n >> 3);
+    for (int g = tid; g < groups; g += ge_bdim()) {
+      const int e = (g << 3) / n, v0 = (g << 3) % n;
+      if (!flag[e]) continue;
+      const uint64_t b8 = (stage[e] >> v0) & 0xffull;
+      uint64_t y = (b8 * 0x0101010101010101ull) & 0x8040201008040201ull;
+      y = ((y + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull;
+      *(uint64_t *)(out + ((int64_t)g << 3)) = y;
+    }
+  } else {
+    const int total = nb * n;
+    for (int idx = tid; idx < total; idx += ge_bdim()) {
+      const int e = idx / n, v = idx % n;
+      if (!flag[e]) continue;
+      out[idx] = (uint8_t)((stage[e] >> v) & 1ull);
+    }
+  }
+}
+
 GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
   int i = ge_bid() * ge_bdim() + ge_tid();
   if (i >= P.B) return;
@@ -264,7 +406,7 @@ GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
   int64_t act = -1;
   for (int w = 0; w < P.AW; w++) {
     uint64_t word = mb[w]; uint32_t pc = (uint32_t)ge_popc64(word);
-    if (r < pc) { for (uint32_t k = 0; k < r; k++) word &= word - 1; act = (int64_t)w * 64 + ge_ctz64(word); break; }
+    if (r < pc) { act = (int64_t)w * 64 + ge_nth_set_bit(word, r); break; }
     r -= pc;
   }
   actions[i] = act;

@@ -122,6 +122,7 @@ class VectorGraphEnv:
         t["edge_attr"] = z((B * E, self.Fe), torch.float32)
         t["row_ptr"] = z((B, n + 1), torch.int32)
         t["colw"] = z((B * E,), torch.int16)
+        t["scode"] = z((B * E,), torch.uint8)
         t["adj_bits"] = z((B * n, W), torch.int64)
         t["rev_edge"] = z((B * E,), torch.int32) if env_id == "SteinerTree-v0" else None
         t["head"] = z((B,), torch.int32)
@@ -145,7 +146,9 @@ class VectorGraphEnv:
         t["final_heur"] = z((B,), torch.float64)
         t["final_len"] = z((B,), torch.int32)
         t["reset_list"] = z((B,), torch.int32)
-        t["reset_count"] = z((4,), torch.int32)
+        t["reset_count"] = z(((B + 255) // 256,), torch.int32)
+        t["work_list"] = z((B,), torch.int32)
+        t["work_count"] = z((4,), torch.int32)
         self.t = t
         bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in t.items()})
         h = C.c_void_p()

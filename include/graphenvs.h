@@ -78,6 +78,8 @@ typedef struct {
   /* --- graph slab (CSR, insertion-order columns) */
   int32_t *row_ptr;     /* [B, n+1]  local offsets into the slot's edge segment             */
   uint16_t *colw;       /* [Ne]      (col << 4) | weight code k, weight = k/10.0 (k=10: 1.0) */
+  uint8_t *scode;       /* [Ne]      weight codes in ascending-neighbour order per row: the code of u->v sits at
+                                     row_ptr[u] + popcount(adj_bits[u] & below(v)) -- a lookup without a row scan */
   uint64_t *adj_bits;   /* [Nn, W]   adjacency bit rows                                     */
   int32_t *rev_edge;    /* [Ne]      SteinerTree: local index of the reverse directed edge (else NULL) */
   /* --- per-slot dynamic state */
@@ -103,8 +105,10 @@ typedef struct {
   double *final_heur;   /* [B]  info['heuristic_solution'] where terminated                  */
   int32_t *final_len;   /* [B]  episode length where terminated                              */
   /* --- reset work queue */
-  int32_t *reset_list;  /* [B]                                                               */
-  int32_t *reset_count; /* [4]  [0] = entries in reset_list                                  */
+  int32_t *reset_list;  /* [B]  step workgroup g (256 slots) lists its finished slots at [256g, 256g+count) */
+  int32_t *reset_count; /* [ceil(B/256)] finished slots per step workgroup, rewritten by every step    */
+  int32_t *work_list;   /* [B]  slots the n<=64 feature fast path hands to the generic feature kernel  */
+  int32_t *work_count;  /* [4]  [0] = entries in work_list                                             */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;

@@ -10,23 +10,32 @@ CSRC = os.path.join(ROOT, "graphenvs_amd", "csrc")
 OUT = os.path.join(HERE, "libgraphenvs_emu.so")
 
 
-def build(force=False):
+def build(force=False, extra=(), out=None):
+    global OUT
+    if out is not None:
+        OUT_ = out
+    else:
+        OUT_ = OUT
+    return _build(force, list(extra), OUT_)
+
+
+def _build(force, extra, OUT):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.h"),
                                                                os.path.join(ROOT, "include", "graphenvs.h")]
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(s) for s in srcs):
         return OUT
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DGE_EMU", "-x", "c++", "-ffp-contract=off",
            "-I" + HERE, "-I" + CSRC, "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
-           "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
+           "-fsanitize=undefined", "-fno-sanitize-recover=undefined", *extra,
            os.path.join(CSRC, "ge_api.hip"), "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 
 
-def load():
+def load(extra=(), out=None):
     sys.path.insert(0, ROOT)
     from graphenvs_amd import _lib
-    return _lib.bind(ctypes.CDLL(build()))
+    return _lib.bind(ctypes.CDLL(build(extra=extra, out=out)))
 
 
 if __name__ == "__main__":

@@ -146,6 +146,7 @@ GE_DEV int ge_bdim() { return ge_emu::blk().nthreads; }
 GE_DEV int ge_gdim() { return ge_emu::blk().gdim; }
 GE_DEV unsigned char *ge_dyn_smem() { return ge_emu::blk().smem; }
 GE_DEV void ge_sync() { ge_emu::barrier(); }
+GE_DEV void ge_wave_sync() { ge_emu::wave_rendezvous(0); }
 
 GE_DEV uint64_t ge_ballot(bool p) {
   using namespace ge_emu;

@@ -61,3 +61,27 @@ def test_emulated_batch_autoreset_matches_oracle(emu):
         for i, r in enumerate(refs):
             assert np.array_equal(flat[i], r.obs())
     assert sum(eps) > B
+
+
+@pytest.mark.parametrize("env_id,kw", [("ShortestPath-v0", dict(n_nodes=12, n_edges=30)),
+                                       ("LongestPath-v0", dict(n_nodes=12, n_edges=30, parenting=1)),
+                                       ("SteinerTree-v0", dict(n_nodes=12, n_edges=30, n_dests=3))])
+def test_emulated_fused_rollout_equals_sample_then_step(emu, env_id, kw):
+    import torch
+    a = ge.VectorGraphEnv(env_id, 70, device="cpu", _library=emu, obs_mode="flat", **kw)
+    b = ge.VectorGraphEnv(env_id, 70, device="cpu", _library=emu, obs_mode="flat", **kw)
+    a.reset(seed=1); b.reset(seed=1)
+    for k in range(25):
+        a.step(a.sample_random_actions(policy_seed=4).clone())
+        b.random_rollout(1, policy_seed=4)
+        for key in ("reward", "terminated", "mask", "mask_bits", "head", "node_bits", "cost", "episode", "tstep", "x", "solved"):
+            assert torch.equal(a.t[key], b.t[key]), (k, key)
+    assert int(a.t["episode"].sum()) > 0
+
+
+def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep():
+    """-DGE_F64_LV=3 forces the lane-per-source path to hand deep slots to the generic kernel."""
+    lib = build_emu.load(extra=["-DGE_F64_LV=3"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_lv3.so"))
+    for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1"]:
+        case = gu.load_case(name)
+        gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))

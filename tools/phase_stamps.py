@@ -19,7 +19,7 @@ L = _lib.bind(C.CDLL(out))
 L.ge_debug_read_stamps.argtypes = [C.c_void_p]
 import graphenvs_amd as ge  # noqa: E402
 
-names = ["seed_py", "topology", "csr", "seed_np", "weights", "terminals", "baseline", "sort+init", "bfs(bc,clos)+clust", "pagerank", "writeout"]
+names = {0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B load+zero", 12: "B bfs forward", 13: "B backward", 14: "B bc/clos/clust", 15: "B pagerank", 16: "B write"}
 cfgs = [("ShortestPath-v0", dict(n_nodes=64, n_edges=192), [1, 4096, 65536])]
 if len(sys.argv) > 1 and sys.argv[1] == "all":
     cfgs += [("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), [1, 2048]),
@@ -32,7 +32,9 @@ for env_id, kw, Bs in cfgs:
             torch.cuda.synchronize()
         buf = (C.c_ulonglong * 32)()
         L.ge_debug_read_stamps(buf)
-        ts = [buf[k] for k in range(12)]
-        print(f"{env_id} {kw} B={B}: total {(ts[11]-ts[0])/100:.1f} us")
-        for k, nm in enumerate(names):
-            print(f"    {nm:22s} {(ts[k+1]-ts[k])/100:9.1f} us")
+        ts = [buf[k] for k in range(32)]
+        print(f"{env_id} {kw} B={B}:")
+        for k, nm in names.items():
+            nxt = k + 1 if k != 6 else 9
+            if ts[k] and ts[nxt]:
+                print(f"    {nm:22s} {(ts[nxt]-ts[k])/100:9.1f} us")
