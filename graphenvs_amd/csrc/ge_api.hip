@@ -51,8 +51,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (t == GE_STEINER_TREE && (cfg->n_dests < 1 || cfg->n_dests > n - 1)) return fail(GE_E_BADARG, "n_dests must be in [1, n_nodes-1]");
   // not built yet
   if (t == GE_TSP && cfg->spatial) return fail(GE_E_UNSUPPORTED, "spatial TSP is not built yet");
-  if (t == GE_LONGEST_PATH && cfg->parenting >= 2) return fail(GE_E_UNSUPPORTED, "LongestPath parenting >= 2 is not built yet");
-  if (t == GE_TSP && cfg->parenting == 2) return fail(GE_E_UNSUPPORTED, "TSP parenting 2 is not built yet");
+  if ((t == GE_LONGEST_PATH || t == GE_TSP) && cfg->parenting >= 2 && n > 64 * GE_MAXW) return fail(GE_E_UNSUPPORTED, "parenting >= 2 is built for n_nodes <= 512");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
   P.nflag = (t == GE_TSP) ? 4 : (t == GE_DENSEST_SUBGRAPH ? 1 : 2);  // utils.py:32-73
@@ -183,7 +182,7 @@ static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P
 extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream);
 
 static bool path64(const ge_engine *e) {
-  return (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1;
+  return (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1 && e->P.parenting < 2;
 }
 
 extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {

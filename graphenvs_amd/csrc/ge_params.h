@@ -22,7 +22,7 @@ struct GeLds {
   int dist;     // i32[n]
   int perm;     // i32[n]
   int f64a;     // f64[2][n] Dijkstra distances (sigma, delta); also stages the first mask words
-  int bits;     // u64[4][W] frontier / visited / next / scratch
+  int bits;     // u64[6][W] frontier / visited / next / removed-or-targets / prune / removed (first mask)
   int misc;     // i32[16]
   int pre;      // i32[nblk+1] exclusive prefix of the per-workgroup reset counts
   int total;
@@ -60,7 +60,7 @@ static inline void ge_make_lds(GeParams &P) {
   L.dist = take(P.n * 4);
   L.perm = take(P.n * 4);
   { int need = 2 * P.n * 8, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
-  L.bits = take(4 * P.W * 8);
+  L.bits = take(6 * P.W * 8);
   L.misc = take(16 * 4);
   L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
   L.total = o;

@@ -106,15 +106,14 @@ GE_DEV GeRctx ge_carve(const GeParams &P) {
   return c;
 }
 
-// [nx] is_connected over nodes [0,ng) minus `skip`, as a level-synchronous BFS on the bit rows
-GE_DEV bool ge_connected(const GeRctx &c, int ng, int W, int skip, int lane) {
+// Level-synchronous BFS on the LDS bit rows from `start` over the nodes [0,ng) that are not in `removed`
+// (W words in LDS, may be null).  Leaves the visited set (removed nodes included) in c.bits[W..2W) and returns
+// the number of nodes reached.  Collective over the wave.
+GE_DEV int ge_reach_wave(const GeRctx &c, int ng, int W, int start, const uint64_t *removed, int lane) {
   uint64_t *fr = c.bits, *vis = c.bits + W, *nx = c.bits + 2 * W;
-  int start = (skip == 0) ? 1 : 0;
   if (lane < W) {
     uint64_t s = ((start >> 6) == lane) ? (1ull << (start & 63)) : 0ull;
-    uint64_t v = s;
-    if (skip >= 0 && (skip >> 6) == lane) v |= 1ull << (skip & 63);
-    fr[lane] = s; vis[lane] = v;
+    fr[lane] = s; vis[lane] = s | (removed ? removed[lane] : 0ull);
   }
   ge_sync();
   for (;;) {
@@ -135,9 +134,18 @@ GE_DEV bool ge_connected(const GeRctx &c, int ng, int W, int skip, int lane) {
     ge_sync();
   }
   int cnt = 0;
-  for (int w = 0; w < W; w++) cnt += ge_popc64(vis[w]);
+  for (int w = 0; w < W; w++) cnt += ge_popc64(vis[w] & ~(removed ? removed[w] : 0ull));
   ge_sync();
-  return cnt == ng;
+  return cnt;
+}
+
+// [nx] is_connected over nodes [0,ng) minus `skip`
+GE_DEV bool ge_connected(const GeRctx &c, int ng, int W, int skip, int lane) {
+  uint64_t *rem = c.bits + 3 * W;
+  if (lane < W) rem[lane] = (skip >= 0 && (skip >> 6) == lane) ? (1ull << (skip & 63)) : 0ull;
+  ge_sync();
+  int start = (skip == 0) ? 1 : 0;
+  return ge_reach_wave(c, ng, W, start, rem, lane) == ng - (skip >= 0 ? 1 : 0);
 }
 
 GE_DEV double ge_pw_leaf(const double *a, int n, int lane) {  // numpy pairwise sum, n <= 128
@@ -568,11 +576,38 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   // first mask (reset() -> info['mask'])
   const int A = P.A, AW = P.AW;
   const bool node_started = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+  uint64_t *prune = c.bits + 4 * W;  // parenting >= 2: nodes that stay selectable
+  if (lane < W) prune[lane] = ~0ull;
+  ge_sync();
+  if (t == GE_LONGEST_PATH && P.parenting >= 2) {  // longest_path.py:134-143: has_path(alt_G, k, dest), alt_G = G - src
+    uint64_t *rem = c.bits + 5 * W;
+    if (lane < W) rem[lane] = ((src >> 6) == lane) ? (1ull << (src & 63)) : 0ull;
+    ge_sync();
+    ge_reach_wave(c, n, W, dest, rem, lane);
+    if (lane < W) {
+      uint64_t keep = c.bits[W + lane] & ~rem[lane];
+      if (P.parenting == 3 && n - 1 <= n / 3) keep = ~rem[lane];  // never true for n >= 2; kept for fidelity
+      prune[lane] = keep;
+    }
+    ge_sync();
+  } else if (t == GE_TSP && P.parenting >= 2) {  // tsp.py:181-194: drop v if alt_G - v is disconnected, alt_G = G - start
+    uint64_t *rem = c.bits + 5 * W;
+    for (int v = 1; v < n; v++) {
+      if (!((c.abits[0 * W + (v >> 6)] >> (v & 63)) & 1ull)) continue;  // uniform: candidates are N(start)
+      if (n - 2 == 0) break;
+      if (lane < W) rem[lane] = (lane == 0 ? 1ull : 0ull) | (((v >> 6) == lane) ? (1ull << (v & 63)) : 0ull);
+      ge_sync();
+      int from = (v == 1) ? 2 : 1;
+      int reached = ge_reach_wave(c, n, W, from, rem, lane);
+      if (reached != n - 2 && lane == (v >> 6)) prune[lane] &= ~(1ull << (v & 63));
+      ge_sync();
+    }
+  }
   for (int w = lane; w < AW; w += GE_WAVE) {
     uint64_t mb;
     int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;
     uint64_t full = (hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull);
-    if (t == GE_SHORTEST_PATH || (t == GE_LONGEST_PATH && P.parenting != 0) || t == GE_TSP) mb = c.abits[src * W + w];
+    if (t == GE_SHORTEST_PATH || (t == GE_LONGEST_PATH && P.parenting != 0) || t == GE_TSP) mb = c.abits[src * W + w] & prune[w];
     else if (t == GE_STEINER_TREE) {  // edges leaving src: steiner_tree.py:116-120
       int a = c.rowptr[src], b = c.rowptr[src + 1]; mb = 0;
       int l2 = a > lo ? a : lo, h2 = b < hi ? b : hi;

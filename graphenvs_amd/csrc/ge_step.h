@@ -35,6 +35,31 @@ GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int ti
   if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[ge_bid()] = tot; }
 }
 
+#define GE_MAXW 8  // parenting >= 2 walks the residual graph per thread: node sets of up to 8 words (n <= 512)
+
+// nodes reachable from `start` inside `alive` minus `skip` (skip < 0: none); rows = the slot's adjacency bit rows
+GE_DEV void ge_reach_thread(const uint64_t *rows, int W, const uint64_t *alive, int start, int skip, uint64_t *R) {
+  uint64_t fr[GE_MAXW];
+  for (int w = 0; w < W; w++) { R[w] = 0; fr[w] = 0; }
+  R[start >> 6] = fr[start >> 6] = 1ull << (start & 63);
+  for (;;) {
+    uint64_t nx[GE_MAXW];
+    for (int w = 0; w < W; w++) nx[w] = 0;
+    for (int w = 0; w < W; w++)
+      for (uint64_t f = fr[w]; f; f &= f - 1) {
+        const uint64_t *row = rows + (int64_t)(w * 64 + ge_ctz64(f)) * W;
+        for (int w2 = 0; w2 < W; w2++) nx[w2] |= row[w2];
+      }
+    uint64_t any = 0;
+    for (int w = 0; w < W; w++) {
+      uint64_t m = nx[w] & alive[w] & ~R[w];
+      if (skip >= 0 && (skip >> 6) == w) m &= ~(1ull << (skip & 63));
+      R[w] |= m; fr[w] = m; any |= m;
+    }
+    if (!any) break;
+  }
+}
+
 GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
@@ -81,10 +106,20 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
           G.head[i] = a;
           G.x[(nbase + a) * F + 0] = 1.f;
           uint64_t any = 0;
+          uint64_t alive[GE_MAXW], R[GE_MAXW];
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
+            if (w < GE_MAXW) alive[w] = ge_full_word(n, w) & ~vb;
+          }
+          const bool prune = lp && P.parenting >= 2 && a != dest;  // longest_path.py:134-143 (dest still in alt_G)
+          if (prune) ge_reach_thread(G.adj_bits + nbase * W, W, alive, dest, -1, R);
+          int n_alive = 0;
+          if (lp && P.parenting == 3) for (int w = 0; w < W; w++) n_alive += ge_popc64(alive[w]);
+          for (int w = 0; w < W; w++) {
+            uint64_t vb = G.node_bits[(int64_t)i * W + w];
             uint64_t nm = (lp && P.parenting == 0) ? ge_full_word(A, w) : (G.adj_bits[(nbase + a) * W + w] & ~vb);
+            if (prune) { nm &= R[w]; if (P.parenting == 3 && n_alive <= n / 3) nm |= alive[w]; }
             stage[tid * W + w] = nm; any |= nm;
           }
           wrote_mask = !(lp && P.parenting == 0);
@@ -114,6 +149,32 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
             uint64_t nm = G.adj_bits[(nbase + a) * W + w] & ~vb;
             if (taken < n - 1 && w == 0) nm &= ~1ull;  // start only once everything else is taken (tsp.py:178-179)
             stage[tid * W + w] = nm; any |= nm;
+          }
+          if (P.parenting >= 2 && any) {  // tsp.py:181-194: a move must leave the untaken nodes (start excluded) connected
+            uint64_t alive[GE_MAXW], R[GE_MAXW];
+            int n_alive = 0;
+            for (int w = 0; w < W; w++) {
+              alive[w] = ge_full_word(n, w) & ~G.node_bits[(int64_t)i * W + w];
+              if (w == 0) alive[w] &= ~1ull;
+              n_alive += ge_popc64(alive[w]);
+            }
+            any = 0;
+            bool stop = false;
+            for (int w = 0; w < W; w++) {
+              uint64_t nm = stage[tid * W + w];
+              for (uint64_t cnd = nm; cnd && !stop; cnd &= cnd - 1) {
+                int v = w * 64 + ge_ctz64(cnd);
+                if (v == start) continue;
+                if (n_alive - 1 == 0) { stop = true; break; }  // G_copy has no node left
+                int from = -1;
+                for (int w2 = 0; w2 < W && from < 0; w2++) { uint64_t r = alive[w2]; if ((v >> 6) == w2) r &= ~(1ull << (v & 63)); if (r) from = w2 * 64 + ge_ctz64(r); }
+                ge_reach_thread(G.adj_bits + nbase * W, W, alive, from, v, R);
+                int reached = 0;
+                for (int w2 = 0; w2 < W; w2++) reached += ge_popc64(R[w2]);
+                if (reached != n_alive - 1) nm &= ~(1ull << (v & 63));
+              }
+              stage[tid * W + w] = nm; any |= nm;
+            }
           }
           wrote_mask = true;
           if (!done && !any) { done = 1; reward -= (double)(n * 2); solved = 0; }

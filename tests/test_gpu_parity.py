@@ -39,6 +39,10 @@ CASES = [
     ("SteinerTree-v0", dict(n_nodes=30, n_edges=80, n_dests=29, is_eval_env=True), 32, 60),
     ("TSP-v0", dict(n_nodes=16, n_edges=120, parenting=1), 32, 40),
     ("TSP-v0", dict(n_nodes=20, n_edges=60, parenting=1), 32, 50),
+    ("TSP-v0", dict(n_nodes=14, n_edges=40, parenting=2), 32, 40),
+    ("LongestPath-v0", dict(n_nodes=24, n_edges=50, parenting=2), 48, 40),
+    ("LongestPath-v0", dict(n_nodes=100, n_edges=300, parenting=2), 16, 60),
+    ("ShortestPath-v0", dict(n_nodes=130, n_edges=400, is_eval_env=True), 16, 60),
     ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 64, 60),
     ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=60, parenting=0, is_eval_env=True), 64, 40),
     ("MaxIndependentSet-v0", dict(n_nodes=70, n_edges=200), 64, 150),
