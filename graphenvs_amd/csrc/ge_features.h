@@ -143,17 +143,17 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
 
 // ------------------------------------------------------------------------------------------------
 // n <= 64 fast path.  LDS carve (bytes): abits 512 | lvl LV*512 | sig 64*66*2 | del 64*65*8 |
-// x,y,sinv,diff 4*512 | scode E (TSP only) | pre.
+// x,y,sinv,diff,clos 5*512 | scode E (TSP only) | pre.
 #ifndef GE_F64_LV
 #define GE_F64_LV 12   // BFS levels kept per source; deeper graphs (or sigma > 65535) take the generic path
 #endif
 #define GE_F64_SS 66   // u16 stride of a sigma row  (33 dwords: odd, spreads banks)
 #define GE_F64_SD 65   // f64 stride of a delta row
 
-struct GeF64 { uint64_t *abits, *lvl; uint16_t *sig; double *del, *x, *y, *sinv, *diff; uint8_t *scode; };
+struct GeF64 { uint64_t *abits, *lvl; uint16_t *sig; double *del, *x, *y, *sinv, *diff, *clos; uint8_t *scode; };
 
 GE_HOSTDEV int ge_f64_bytes(int E, int tsp, int nblk) {
-  int o = 512 + GE_F64_LV * 512 + 64 * GE_F64_SS * 2 + 64 * GE_F64_SD * 8 + 4 * 512;
+  int o = 512 + GE_F64_LV * 512 + 64 * GE_F64_SS * 2 + 64 * GE_F64_SD * 8 + 5 * 512;
   o = (o + 15) & ~15;
   if (tsp) o += (E + 15) & ~15;
   return o + (nblk + 2) * 4 + 16;
@@ -165,31 +165,34 @@ GE_DEV GeF64 ge_carve_f64(int E, int tsp) {
   c.abits = (uint64_t *)s; s += 512;
   c.lvl = (uint64_t *)s; s += GE_F64_LV * 512;
   c.del = (double *)s; s += 64 * GE_F64_SD * 8;
-  c.x = (double *)s; s += 512; c.y = (double *)s; s += 512; c.sinv = (double *)s; s += 512; c.diff = (double *)s; s += 512;
+  c.x = (double *)s; s += 512; c.y = (double *)s; s += 512; c.sinv = (double *)s; s += 512; c.diff = (double *)s; s += 512; c.clos = (double *)s; s += 512;
   c.sig = (uint16_t *)s; s += 64 * GE_F64_SS * 2;
   c.scode = (uint8_t *)(((uintptr_t)s + 15) & ~(uintptr_t)15);
   return c;
 }
 GE_DEV int *ge_f64_pre(int E, int tsp, int nblk) { return (int *)(ge_dyn_smem() + ge_f64_bytes(E, tsp, nblk) - (nblk + 2) * 4 - 8); }
 
-// 256-thread workgroup: the Brandes walks are latency-bound chains of LDS round trips, so the 64 sources are
-// spread over four waves (16 lanes each) that run on the CU's four SIMDs; the node-per-lane phases (betweenness
-// reduction, closeness, clustering, pagerank) run on the first wave.  Slots that are too deep or whose path
-// counts exceed 16 bits are appended to work_list for the generic kernel.
-#define GE_F64_THREADS 256
+// 320-thread workgroup.  Waves 0-3 are the walkers: the Brandes walks are chains of LDS round trips, so the 64
+// sources are spread over four waves (16 quads each) on the CU's four SIMDs.  Wave 4 is the node wave (one lane
+// per node): it computes clustering and pagerank WHILE the walkers run their forward pass, then reduces
+// betweenness / closeness and writes the five columns.  Slots that are too deep or whose path counts exceed the
+// 16-bit counters are appended to work_list for the generic kernel.
+#define GE_F64_THREADS 320
+#define GE_F64_WALKERS 256
 GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   const int tid = ge_tid();
-  const int lane = tid;  // node index in the node-per-lane phases (first wave only)
+  const bool node_wave = tid >= GE_F64_WALKERS;
+  const int lane = tid - GE_F64_WALKERS;  // node index inside the node wave
   const int n = P.n, E = P.E, F = P.F, t = P.env_type;
   const ge_buffers &G = P.buf;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   const bool prw = (t == GE_TSP);
   GeF64 c = ge_carve_f64(E, prw);
-  const bool live = lane < n;
+  const bool live = node_wave && lane < n;
   GE_STAMP(11);
   const uint64_t adj = live ? G.adj_bits[nbase + lane] : 0ull;
   const int deg = ge_popc64(adj);
-  if (tid < 64) c.abits[tid] = adj;
+  if (node_wave) c.abits[lane] = adj;
   if (tid == 0) *ovf_flag = 0;
   for (int i = tid; i < 64 * GE_F64_SS / 2; i += GE_F64_THREADS) ((uint32_t *)c.sig)[i] = 0u;
   for (int i = tid; i < 64 * GE_F64_SD; i += GE_F64_THREADS) c.del[i] = 0.0;
@@ -198,107 +201,52 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
 
   GE_STAMP(12);
   // ---- Brandes, lane = source.  Forward: BFS + path counts, pushing sigma along DAG edges.
-  const int s = (tid >> 6) * 16 + (tid & 63);  // source of this thread (lanes 0..15 of each wave)
-  const bool walker = (tid & 63) < 16 && s < n;
+  // Four lanes (a quad) per source, 16 sources per wave: the quad keeps identical copies of the walk state and
+  // splits the pushes of a node -- lane q takes the q-th, (q+4)-th, ... target -- so a node's DAG edges are
+  // served in parallel while the per-source order of the float64 delta sums stays fixed.
+  const int s = (tid >> 6) * 16 + ((tid & 63) >> 2);
+  const int q = tid & 3;
+  const bool walker = !node_wave && s < n;
   bool ovf = false;
   int D = 0, reach = 1; int64_t tot = 0;
   if (walker) {
-    // one node per iteration in every lane (each lane visits its n reachable nodes once); the pushes of a node
-    // go out four at a time so their LDS reads overlap (the targets of one node are distinct: no RMW hazard)
     uint64_t visited = 1ull << s, cur = visited, nxt = 0;
-    c.sig[s * GE_F64_SS + s] = 1;
+    if (q == 0) c.sig[s * GE_F64_SS + s] = 1;
     for (;;) {
       if (cur == 0) {
         if (!nxt) break;
         visited |= nxt; D++;
-        if (D < GE_F64_LV) c.lvl[D * 64 + s] = nxt; else ovf = true;
+        if (D < GE_F64_LV) { if (q == 0) c.lvl[D * 64 + s] = nxt; } else ovf = true;
         const int cnt = ge_popc64(nxt);
         reach += cnt; tot += (int64_t)D * cnt;
         cur = nxt; nxt = 0;
       }
+      ge_quad_sync();  // the quad's pushes of the previous node are in LDS before this node is read
       const int u = ge_ctz64(cur); cur &= cur - 1;
-      const uint32_t su = c.sig[u * GE_F64_SS + s];
+      const uint32_t su = c.sig[u * GE_F64_SS + s];   // final: u's level is complete before it is expanded
+      if (su > 1023u) ovf = true;                     // 64 parents x 1023 still fit the 16-bit counters
       uint64_t cand = c.abits[u] & ~visited;
       nxt |= cand;
       while (cand) {
-        const int v0 = ge_ctz64(cand); cand &= cand - 1;
-        const bool h1 = cand != 0; const int v1 = h1 ? ge_ctz64(cand) : v0; cand &= cand - 1;
-        const bool h2 = cand != 0; const int v2 = h2 ? ge_ctz64(cand) : v0; cand &= cand - 1;
-        const bool h3 = cand != 0; const int v3 = h3 ? ge_ctz64(cand) : v0; cand &= cand - 1;
-        const uint32_t r0 = c.sig[v0 * GE_F64_SS + s], r1 = c.sig[v1 * GE_F64_SS + s];
-        const uint32_t r2 = c.sig[v2 * GE_F64_SS + s], r3 = c.sig[v3 * GE_F64_SS + s];
-        const uint32_t n0 = r0 + su, n1 = r1 + su, n2 = r2 + su, n3 = r3 + su;
-        if ((n0 | (h1 ? n1 : 0u) | (h2 ? n2 : 0u) | (h3 ? n3 : 0u)) > 0xffffu) ovf = true;
-        c.sig[v0 * GE_F64_SS + s] = (uint16_t)n0;
-        if (h1) c.sig[v1 * GE_F64_SS + s] = (uint16_t)n1;
-        if (h2) c.sig[v2 * GE_F64_SS + s] = (uint16_t)n2;
-        if (h3) c.sig[v3 * GE_F64_SS + s] = (uint16_t)n3;
+        const uint64_t t0 = cand, t1 = t0 & (t0 - 1), t2 = t1 & (t1 - 1), t3 = t2 & (t2 - 1);
+        cand = t3 & (t3 - 1);
+        const uint64_t mine = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
+        if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
+          const int idx = ge_ctz64(mine) * GE_F64_SS + s;
+          ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su << (16 * (idx & 1)));
+        }
       }
     }
   }
-  if (ovf) *ovf_flag = 1;
-  ge_sync();
-  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
-    if (tid == 0) { int k = atomicAdd(&G.work_count[0], 1); G.work_list[k] = env; }
-    ge_sync();
-    return;
-  }
-  GE_STAMP(13);
-  // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
-  if (walker) {
-    int d = D;
-    uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
-    uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
-    while (d >= 1) {
-      if (cur == 0) {
-        d--;
-        if (d >= 1) { cur = c.lvl[d * 64 + s]; prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s); }
-        continue;
-      }
-      const int w = ge_ctz64(cur); cur &= cur - 1;
-      const double coeff = (1.0 + c.del[w * GE_F64_SD + s]) / (double)c.sig[w * GE_F64_SS + s];
-      uint64_t pb = c.abits[w] & prev;
-      while (pb) {  // predecessors of w are distinct nodes: four independent read-modify-writes per round
-        const int v0 = ge_ctz64(pb); pb &= pb - 1;
-        const bool h1 = pb != 0; const int v1 = h1 ? ge_ctz64(pb) : v0; pb &= pb - 1;
-        const bool h2 = pb != 0; const int v2 = h2 ? ge_ctz64(pb) : v0; pb &= pb - 1;
-        const bool h3 = pb != 0; const int v3 = h3 ? ge_ctz64(pb) : v0; pb &= pb - 1;
-        const double s0 = (double)c.sig[v0 * GE_F64_SS + s], s1 = (double)c.sig[v1 * GE_F64_SS + s];
-        const double s2 = (double)c.sig[v2 * GE_F64_SS + s], s3 = (double)c.sig[v3 * GE_F64_SS + s];
-        const double d0 = c.del[v0 * GE_F64_SD + s], d1 = c.del[v1 * GE_F64_SD + s];
-        const double d2 = c.del[v2 * GE_F64_SD + s], d3 = c.del[v3 * GE_F64_SD + s];
-        c.del[v0 * GE_F64_SD + s] = d0 + s0 * coeff;
-        if (h1) c.del[v1 * GE_F64_SD + s] = d1 + s1 * coeff;
-        if (h2) c.del[v2 * GE_F64_SD + s] = d2 + s2 * coeff;
-        if (h3) c.del[v3 * GE_F64_SD + s] = d3 + s3 * coeff;
-      }
-    }
-  }
-  // closeness (wf_improved) of source s, handed to the node-per-lane phase through LDS
-  if (walker) {
-    double cl = 0.0;
-    if (tot > 0 && n > 1) { cl = ((double)reach - 1.0) / (double)tot; cl *= ((double)reach - 1.0) / (double)(n - 1); }
-    c.y[s] = cl;
-  }
-  ge_sync();
-  GE_STAMP(14);
-  if (tid < 64) {  // the remaining phases are one wave wide: wave-level LDS hand-offs only
-  // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
-  double bc = 0.0;
-  if (live) {
-    for (int src = 0; src < n; src++) if (src != lane) bc += c.del[lane * GE_F64_SD + src];
-    if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
-  }
-  const double clos = live ? c.y[lane] : 0.0;
+  double clus = 0.0, x = 0.0;
+  if (node_wave) {  // concurrent with the walkers' forward pass
   // clustering (directed formula on the symmetric graph)
-  double clus = 0.0;
   if (live) {
     int64_t common = 0;
     for (uint64_t r = adj; r; r &= r - 1) common += ge_popc64(adj & c.abits[ge_ctz64(r)]);
     const int64_t t8 = 8 * common, dt = 2 * (int64_t)deg, db = deg;
     clus = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
   }
-  GE_STAMP(15);
   // pagerank ([nx] _pagerank_scipy): x_new[i] = sum over in-neighbours j ascending of (sinv[j]*w_ji) * x[j]
   int rp = 0;  // row start in ascending-neighbour order = exclusive scan of degrees
   if (prw) { int incl = ge_wave_incl_scan(deg, lane); rp = incl - deg; }
@@ -308,7 +256,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   const double pinit = 1.0 / (double)n;
   const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
   const uint64_t dangling = ge_ballot(live && deg == 0);
-  double x = pinit;
+  x = pinit;
   c.sinv[lane] = sinv;
   bool conv = false;
   for (int it = 0; it < 100 && !conv; it++) {
@@ -330,6 +278,60 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
     ge_wave_sync();
     if (err < (double)n * tol) conv = true;
   }
+  }
+  if (ovf) *ovf_flag = 1;
+  ge_sync();
+  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
+    if (tid == 0) { int k = atomicAdd(&G.work_count[0], 1); G.work_list[k] = env; }
+    ge_sync();
+    return;
+  }
+  GE_STAMP(13);
+  // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
+  if (walker) {
+    int d = D;
+    uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
+    uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
+    while (d >= 1) {
+      if (cur == 0) {
+        d--;
+        if (d >= 1) { cur = c.lvl[d * 64 + s]; prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s); }
+        continue;
+      }
+      ge_quad_sync();
+      const int w = ge_ctz64(cur); cur &= cur - 1;
+      // del[w] holds S = sum of coeff over w's DAG successors (all processed: deeper level first);
+      // delta[w] = sigma[w] * S, stored for the betweenness sum, and coeff[w] = (1 + delta[w]) / sigma[w]
+      const double sg = (double)c.sig[w * GE_F64_SS + s];
+      const double dw = sg * c.del[w * GE_F64_SD + s];
+      ge_quad_sync();  // every lane of the quad has read S before lane 0 replaces it by delta[w]
+      if (q == 0) c.del[w * GE_F64_SD + s] = dw;
+      const double coeff = (1.0 + dw) / sg;
+      uint64_t pb = c.abits[w] & prev;
+      while (pb) {
+        const uint64_t t0 = pb, t1 = t0 & (t0 - 1), t2 = t1 & (t1 - 1), t3 = t2 & (t2 - 1);
+        pb = t3 & (t3 - 1);
+        const uint64_t mine = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
+        if (mine) ge_lds_add_f64(&c.del[ge_ctz64(mine) * GE_F64_SD + s], coeff);  // ds_add_f64, fire and forget
+      }
+    }
+  }
+  // closeness (wf_improved) of source s, handed to the node-per-lane phase through LDS
+  if (walker && q == 0) {
+    double cl = 0.0;
+    if (tot > 0 && n > 1) { cl = ((double)reach - 1.0) / (double)tot; cl *= ((double)reach - 1.0) / (double)(n - 1); }
+    c.clos[s] = cl;
+  }
+  ge_sync();
+  GE_STAMP(14);
+  if (node_wave) {  // betweenness / closeness reduction and the write, one lane per node
+  // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
+  double bc = 0.0;
+  if (live) {
+    for (int src = 0; src < n; src++) if (src != lane) bc += c.del[lane * GE_F64_SD + src];
+    if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
+  }
+  const double clos = live ? c.clos[lane] : 0.0;
   GE_STAMP(16);
   if (live) {
     float *xr = G.x + (nbase + lane) * F + P.nflag;

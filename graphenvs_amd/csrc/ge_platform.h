@@ -25,6 +25,12 @@ GE_DEV unsigned char *ge_dyn_smem() {
 GE_DEV void ge_sync() { __syncthreads(); }
 // LDS hand-off between lanes of ONE wave (the other waves of the workgroup do not take part)
 GE_DEV void ge_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// Ordering point between the four lanes of a quad that execute identical control flow: LDS operations of one wave
+// are performed in issue order, so only the compiler has to be kept from moving accesses across this point.
+GE_DEV void ge_quad_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// fire-and-forget LDS adds (ds_add_u32 / ds_add_f64, no return value, nothing to wait for)
+GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
+GE_DEV void ge_lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 GE_DEV uint64_t ge_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 GE_DEV int ge_shfl_i32(int v, int src) { return __shfl(v, src, 64); }
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }

@@ -573,6 +573,15 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
   for (int v = lane; v <= n; v += GE_WAVE) G.row_ptr[(int64_t)env * (n + 1) + v] = c.rowptr[v];
   for (int i = lane; i < n * W; i += GE_WAVE) G.adj_bits[nbase * W + i] = c.abits[i];
+  if (G.node_rec) {  // W == 1: {bit row, nibble-packed codes of the 16 smallest neighbours}
+    for (int v = lane; v < n; v += GE_WAVE) {
+      uint64_t codes = 0; int d = c.rowptr[v + 1] - c.rowptr[v]; if (d > 16) d = 16;
+      for (int k = 0; k < d; k++) codes |= (uint64_t)(c.wsort[c.rowptr[v] + k] & 15) << (4 * k);
+      G.node_rec[(nbase + v) * 2] = c.abits[v]; G.node_rec[(nbase + v) * 2 + 1] = codes;
+      const int h0 = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 0 : src;
+      if (v == h0) { G.cur_rec[(int64_t)env * 2] = c.abits[v]; G.cur_rec[(int64_t)env * 2 + 1] = codes; }
+    }
+  }
   // first mask (reset() -> info['mask'])
   const int A = P.A, AW = P.AW;
   const bool node_started = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);

@@ -355,6 +355,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
     uint64_t vis = G.node_bits[i];
     const int64_t ts = G.tstep[i];
     const int len0 = G.counters[2 * i + 1];
+    const ulonglong2 crec = ((const ulonglong2 *)G.cur_rec)[i];
     int64_t a64;
     if (SAMPLE) {
       uint32_t cnt = (uint32_t)ge_popc64(mb);
@@ -369,16 +370,20 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
     }
     const bool in_range = a64 >= 0 && a64 < (int64_t)n;
     const int a = in_range ? (int)a64 : 0;
-    // round 2: bit rows of head and action, row start (gathers inside the slot's slab)
+    // round 2: ONE 16-byte gather -- the record of the chosen node (its bit row and its packed weight codes).
+    // The head's record travels in the coalesced slot state (cur_rec), so the reward needs no row_ptr / scode gather.
     const int64_t nbase = (int64_t)i * n;
-    const uint64_t adjH = (GE_ABL & 4) ? (mb | 2) : G.adj_bits[nbase + head];
-    const uint64_t adjA = (GE_ABL & 4) ? (mb * 3) : G.adj_bits[nbase + a];
-    const int rp = (GE_ABL & 4) ? head : G.row_ptr[(int64_t)i * (n + 1) + head];
-    // round 3: weight code by rank (valid only when a is a neighbour of head)
+    const uint64_t adjH = (GE_ABL & 4) ? (mb | 2) : crec.x;
+    const ulonglong2 arec = (GE_ABL & 4) ? make_ulonglong2(mb * 3, 0x3333333333333333ull) : ((const ulonglong2 *)G.node_rec)[nbase + a];
+    const uint64_t adjA = arec.x;
     const bool nbr = (adjH >> a) & 1ull;
-    int pos = rp + ge_popc64(adjH & ((1ull << a) - 1ull));
-    if (pos >= P.E) pos = P.E - 1;
-    const int code = (GE_ABL & 8) ? 3 + (pos & 3) : G.scode[(int64_t)i * P.E + pos];
+    const int rank = ge_popc64(adjH & ((1ull << a) - 1ull));
+    int code = (int)((crec.y >> (4 * (rank & 15))) & 15ull);
+    if (ge_popc64(adjH) > 16) {  // rare: the head has more than 16 neighbours -> rank-indexed byte in the scode slab
+      int pos = G.row_ptr[(int64_t)i * (n + 1) + head] + rank;
+      if (pos >= P.E) pos = P.E - 1;
+      code = G.scode[(int64_t)i * P.E + pos];
+    }
 
     double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
     if (st == 0 && a64 != -1) {
@@ -397,6 +402,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
           if (!(GE_ABL & 1)) G.x[(nbase + a) * F + 0] = 1.f;
           vis |= 1ull << a;
           G.node_bits[i] = vis;
+          ((ulonglong2 *)G.cur_rec)[i] = arec;
           const uint64_t nm = open_mask ? mb : (adjA & ~vis);
           stage[tid] = nm;
           wrote_mask = !open_mask;

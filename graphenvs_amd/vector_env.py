@@ -124,8 +124,10 @@ class VectorGraphEnv:
         t["colw"] = z((B * E,), torch.int16)
         t["scode"] = z((B * E,), torch.uint8)
         t["adj_bits"] = z((B * n, W), torch.int64)
+        t["node_rec"] = z((B * n, 2), torch.int64) if W == 1 else None
         t["rev_edge"] = z((B * E,), torch.int32) if env_id == "SteinerTree-v0" else None
         t["head"] = z((B,), torch.int32)
+        t["cur_rec"] = z((B, 2), torch.int64) if W == 1 else None
         t["terminals"] = z((B, T), torch.int32)
         t["node_bits"] = z((B, W), torch.int64)
         t["target_bits"] = z((B, W), torch.int64)

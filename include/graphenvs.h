@@ -81,9 +81,12 @@ typedef struct {
   uint8_t *scode;       /* [Ne]      weight codes in ascending-neighbour order per row: the code of u->v sits at
                                      row_ptr[u] + popcount(adj_bits[u] & below(v)) -- a lookup without a row scan */
   uint64_t *adj_bits;   /* [Nn, W]   adjacency bit rows                                     */
+  uint64_t *node_rec;   /* [Nn, 2]   n <= 64 only: {bit row, weight codes of the 16 smallest neighbours as nibbles}:
+                                     everything a step needs about a node in one 16-byte gather (else NULL) */
   int32_t *rev_edge;    /* [Ne]      SteinerTree: local index of the reverse directed edge (else NULL) */
   /* --- per-slot dynamic state */
   int32_t *head;        /* [B]  path head / TSP head                                        */
+  uint64_t *cur_rec;    /* [B, 2] node_rec of the head, carried in the coalesced slot state (else NULL) */
   int32_t *terminals;   /* [B, T] T = max(2, n_dests+1): src, dest(s)                        */
   uint64_t *node_bits;  /* [B, W] visited / in-tree / taken set                              */
   uint64_t *target_bits;/* [B, W] SteinerTree: targets                                       */

@@ -50,7 +50,7 @@ struct Fiber {
   ucontext_t ctx;
   char *stack = nullptr;
   bool done = true;
-  int waiting = 0;  // 0 runnable, 1 block barrier, 2 wave collective
+  int waiting = 0;  // 0 runnable, 1 block barrier, 2 wave collective, 3 quad rendezvous
 };
 
 struct Block {
@@ -116,6 +116,11 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
       for (int t = w * kWave; t < nthreads && t < (w + 1) * kWave; t++) if (!b.fib[t].done) { wl++; if (b.fib[t].waiting == 2) ww++; }
       if (wl && ww == wl) { for (int t = w * kWave; t < nthreads && t < (w + 1) * kWave; t++) if (b.fib[t].waiting == 2) b.fib[t].waiting = 0; b.wave_gen[w]++; released = true; }
     }
+    for (int q0 = 0; q0 < nthreads; q0 += 4) {  // quads (4 consecutive lanes running identical control flow)
+      int ql = 0, qw = 0;
+      for (int t = q0; t < nthreads && t < q0 + 4; t++) if (!b.fib[t].done) { ql++; if (b.fib[t].waiting == 3) qw++; }
+      if (ql && qw == ql) { for (int t = q0; t < nthreads && t < q0 + 4; t++) if (b.fib[t].waiting == 3) b.fib[t].waiting = 0; released = true; }
+    }
     if (!progressed && !released) die("deadlock: a barrier or wave collective was not reached by every live lane (divergent rendezvous)");
   }
 }
@@ -147,6 +152,7 @@ GE_DEV int ge_gdim() { return ge_emu::blk().gdim; }
 GE_DEV unsigned char *ge_dyn_smem() { return ge_emu::blk().smem; }
 GE_DEV void ge_sync() { ge_emu::barrier(); }
 GE_DEV void ge_wave_sync() { ge_emu::wave_rendezvous(0); }
+GE_DEV void ge_quad_sync() { ge_emu::Block &b = ge_emu::blk(); b.fib[b.cur].waiting = 3; ge_emu::yield_to_sched(); }
 
 GE_DEV uint64_t ge_ballot(bool p) {
   using namespace ge_emu;
@@ -170,6 +176,8 @@ GE_DEV int ge_shfl_i32(int v, int src) { return (int)(int64_t)ge_shfl_u64((uint6
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)ge_shfl_u64(v, src); }
 GE_DEV double ge_shfl_f64(double v, int src) { uint64_t u; memcpy(&u, &v, 8); u = ge_shfl_u64(u, src); memcpy(&v, &u, 8); return v; }
 
+GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
+GE_DEV void ge_lds_add_f64(double *p, double v) { *p += v; }
 GE_DEV int ge_popc64(uint64_t v) { return __builtin_popcountll(v); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
@@ -181,3 +189,6 @@ template <class T> GE_DEV T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; 
 #define GE_LAUNCH(kernel, grid, block, smem, stream, ...) \
   ge_emu::launch((int)(grid), (int)(block), (size_t)(smem), [=]() { kernel(__VA_ARGS__); })
 #define GE_SET_MAX_DYN_LDS(kernel, bytes) (0)
+
+struct ulonglong2 { unsigned long long x, y; };
+static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }

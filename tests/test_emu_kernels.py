@@ -86,3 +86,26 @@ def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep():
     for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1"]:
         case = gu.load_case(name)
         gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
+
+
+def test_emulated_dense_rows_use_the_scode_fallback(emu):
+    """degree > 16: the nibble-packed node record cannot hold the row, the step falls back to row_ptr + scode."""
+    import oracle
+    B, n, m = 5, 24, 230
+    env = ge.VectorGraphEnv("ShortestPath-v0", B, n, m, device="cpu", _library=emu, obs_mode="flat", autoreset=False)
+    env.reset(seed=2)
+    refs = [oracle.OracleEnv("ShortestPath-v0", n_nodes=n, n_edges=m) for _ in range(B)]
+    for i, r in enumerate(refs):
+        r.reset(seed=2 + i)
+    assert max(int(bin(int(v) & (2**64 - 1)).count("1")) for v in env.t["adj_bits"].flatten().tolist()) > 16
+    alive = [True] * B
+    for k in range(12):
+        a = env.sample_random_actions(policy_seed=1).clone().numpy()
+        _, rew, term, _, info = env.step(a)
+        for i, r in enumerate(refs):
+            if not alive[i]:
+                continue
+            _, rr, dd, _, _ = r.step(int(a[i]))
+            assert float(rew[i]) == rr and bool(term[i]) == dd
+            assert np.array_equal(info["mask"][i].numpy(), r.mask())
+            alive[i] = not dd
