@@ -58,7 +58,7 @@ class GeBuffers(C.Structure):
 SYMBOLS = [
     "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_reset", "ge_step", "ge_step_only",
     "ge_reset_pending", "ge_inject_state", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
-    "ge_timed_rollout", "ge_last_error",
+    "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error",
 ]
 
 
@@ -111,6 +111,8 @@ def bind(lib):
     lib.ge_timed_rollout.restype = C.c_int
     lib.ge_timed_rollout.argtypes = [vp, u64, i32, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+    lib.ge_timed_step_burst.restype = C.c_int
+    lib.ge_timed_step_burst.argtypes = [vp, u64, i32, vp, vp, C.POINTER(C.c_double)]
     lib.ge_last_error.restype = C.c_char_p
     lib.ge_last_error.argtypes = []
     return lib

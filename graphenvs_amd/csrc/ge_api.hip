@@ -275,6 +275,20 @@ extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_st
   return GE_OK;
 }
 
+extern "C" int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k, int64_t *scratch, void *stream, double *burst_ms) {
+  if (!e || !scratch || !burst_ms) return fail(GE_E_BADARG, "null argument");
+  if (!e->have_events) { for (int j = 0; j < 4; j++) if (hipEventCreate(&e->ev[j]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventCreate failed"); e->have_events = true; }
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipEventRecord(e->ev[0], st);
+  for (int j = 0; j < k; j++) { int rc = sample_and_step(e, policy_seed, scratch, stream); if (rc != GE_OK) return rc; }
+  (void)hipEventRecord(e->ev[1], st);
+  if (hipEventSynchronize(e->ev[1]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventSynchronize failed");
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
+  *burst_ms = ms;
+  return GE_OK;
+}
+
 #if defined(GE_STAMPS) && !defined(GE_EMU)
 // diagnostic build only: copy out the phase timestamps of slot 0 (synchronises)
 extern "C" int ge_debug_read_stamps(unsigned long long *out32) {

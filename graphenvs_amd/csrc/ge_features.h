@@ -221,19 +221,29 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
         reach += cnt; tot += (int64_t)D * cnt;
         cur = nxt; nxt = 0;
       }
-      ge_quad_sync();  // the quad's pushes of the previous node are in LDS before this node is read
+      ge_quad_sync();  // the quad's pushes of the previous nodes are in LDS before these nodes are read
+      // two nodes of the current level per iteration: their counts are final, their pushes are commutative adds
       const int u = ge_ctz64(cur); cur &= cur - 1;
-      const uint32_t su = c.sig[u * GE_F64_SS + s];   // final: u's level is complete before it is expanded
-      if (su > 1023u) ovf = true;                     // 64 parents x 1023 still fit the 16-bit counters
-      uint64_t cand = c.abits[u] & ~visited;
-      nxt |= cand;
-      while (cand) {
+      const bool two = cur != 0;
+      const int u2 = two ? ge_ctz64(cur) : u; cur &= cur - 1;
+      const uint32_t su = c.sig[u * GE_F64_SS + s], su2 = c.sig[u2 * GE_F64_SS + s];
+      if ((su | su2) > 1023u) ovf = true;            // 64 parents x 1023 still fit the 16-bit counters
+      uint64_t cand = c.abits[u] & ~visited, cand2 = two ? (c.abits[u2] & ~visited) : 0ull;
+      nxt |= cand | cand2;
+      while (cand | cand2) {
         const uint64_t t0 = cand, t1 = t0 & (t0 - 1), t2 = t1 & (t1 - 1), t3 = t2 & (t2 - 1);
         cand = t3 & (t3 - 1);
+        const uint64_t r0 = cand2, r1 = r0 & (r0 - 1), r2 = r1 & (r1 - 1), r3 = r2 & (r2 - 1);
+        cand2 = r3 & (r3 - 1);
         const uint64_t mine = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
+        const uint64_t mine2 = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;
         if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
           const int idx = ge_ctz64(mine) * GE_F64_SS + s;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su << (16 * (idx & 1)));
+        }
+        if (mine2) {
+          const int idx = ge_ctz64(mine2) * GE_F64_SS + s;
+          ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su2 << (16 * (idx & 1)));
         }
       }
     }
@@ -279,16 +289,12 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
     if (err < (double)n * tol) conv = true;
   }
   }
+  // No barrier between the passes: the backward pass only touches the lane's own source columns.  A slot that
+  // overflowed is discarded as a whole after the last barrier (the generic kernel recomputes it).
   if (ovf) *ovf_flag = 1;
-  ge_sync();
-  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
-    if (tid == 0) { int k = atomicAdd(&G.work_count[0], 1); G.work_list[k] = env; }
-    ge_sync();
-    return;
-  }
   GE_STAMP(13);
   // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
-  if (walker) {
+  if (walker && !ovf) {
     int d = D;
     uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
     uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
@@ -299,20 +305,28 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
         continue;
       }
       ge_quad_sync();
+      // two nodes of the level per iteration (independent division chains overlap).  del[w] holds S = sum of coeff
+      // over w's DAG successors (deeper level, finished); delta[w] = sigma[w] * S is stored for the betweenness sum
+      // and coeff[w] = (1 + delta[w]) / sigma[w] is pushed to w's predecessors.
       const int w = ge_ctz64(cur); cur &= cur - 1;
-      // del[w] holds S = sum of coeff over w's DAG successors (all processed: deeper level first);
-      // delta[w] = sigma[w] * S, stored for the betweenness sum, and coeff[w] = (1 + delta[w]) / sigma[w]
-      const double sg = (double)c.sig[w * GE_F64_SS + s];
-      const double dw = sg * c.del[w * GE_F64_SD + s];
-      ge_quad_sync();  // every lane of the quad has read S before lane 0 replaces it by delta[w]
-      if (q == 0) c.del[w * GE_F64_SD + s] = dw;
-      const double coeff = (1.0 + dw) / sg;
-      uint64_t pb = c.abits[w] & prev;
-      while (pb) {
+      const bool two = cur != 0;
+      const int w2 = two ? ge_ctz64(cur) : w; cur &= cur - 1;
+      const double sg = (double)c.sig[w * GE_F64_SS + s], sg2 = (double)c.sig[w2 * GE_F64_SS + s];
+      const double dw = sg * c.del[w * GE_F64_SD + s], dw2 = sg2 * c.del[w2 * GE_F64_SD + s];
+      ge_quad_sync();  // every lane of the quad has read S before lane 0 replaces it by delta
+      if (q == 0) { c.del[w * GE_F64_SD + s] = dw; if (two) c.del[w2 * GE_F64_SD + s] = dw2; }
+      const double coeff = (1.0 + dw) / sg, coeff2 = (1.0 + dw2) / sg2;
+      uint64_t pb = c.abits[w] & prev, pb2 = two ? (c.abits[w2] & prev) : 0ull;
+      while (pb | pb2) {
         const uint64_t t0 = pb, t1 = t0 & (t0 - 1), t2 = t1 & (t1 - 1), t3 = t2 & (t2 - 1);
         pb = t3 & (t3 - 1);
+        const uint64_t r0 = pb2, r1 = r0 & (r0 - 1), r2 = r1 & (r1 - 1), r3 = r2 & (r2 - 1);
+        pb2 = r3 & (r3 - 1);
         const uint64_t mine = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
+        const uint64_t mine2 = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;
         if (mine) ge_lds_add_f64(&c.del[ge_ctz64(mine) * GE_F64_SD + s], coeff);  // ds_add_f64, fire and forget
+        ge_quad_sync();  // same-target adds of w and w2 keep their order (w first) in every run
+        if (mine2) ge_lds_add_f64(&c.del[ge_ctz64(mine2) * GE_F64_SD + s], coeff2);
       }
     }
   }
@@ -324,6 +338,11 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   }
   ge_sync();
   GE_STAMP(14);
+  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
+    if (tid == 0) { int k = atomicAdd(&G.work_count[0], 1); G.work_list[k] = env; }
+    ge_sync();
+    return;
+  }
   if (node_wave) {  // betweenness / closeness reduction and the write, one lane per node
   // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
   double bc = 0.0;

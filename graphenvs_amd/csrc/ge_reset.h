@@ -35,41 +35,48 @@ GE_DEV void ge_mt_twist(uint32_t *mt, int lane) {
       int im = i + GE_MT_M; if (im >= GE_MT_N) im -= GE_MT_N;
       a = mt[i]; b = mt[i1]; c = mt[im];
     }
-    ge_sync();
+    ge_wave_sync();
     if (ok) {
       uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
       mt[i] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     }
-    ge_sync();
+    ge_wave_sync();
   }
 }
 
-// random.seed(int) for 0 <= s < 2^32: init_by_array([s]) ([py] _randommodule.c). One lane.
-GE_DEV void ge_mt_seed_python(uint32_t *mt, uint32_t seed) {
-  uint32_t b = 19650218u, prev = b;
-  mt[0] = b;
-  for (int i = 1; i < GE_MT_N; i++) {
-    b = 1812433253u * (b ^ (b >> 30)) + (uint32_t)i;            // init_genrand(19650218)[i]
-    prev = (b ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;      // + key[0] + j, j == 0
-    mt[i] = prev;
+// random.seed(int) for 0 <= s < 2^32: init_by_array([s]) ([py] _randommodule.c).  1 246 dependent steps, run by
+// lane 0 on the vector ALU (measured: the scalar-ALU form of the same chain is 1.6x slower on gfx950).  Collective.
+GE_DEV void ge_mt_seed_python(uint32_t *mt, uint32_t seed, int lane) {
+  if (lane == 0) {
+    uint32_t b = 19650218u, prev = b;
+    mt[0] = b;
+    for (int i = 1; i < GE_MT_N; i++) {
+      b = 1812433253u * (b ^ (b >> 30)) + (uint32_t)i;            // init_genrand(19650218)[i]
+      prev = (b ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;      // + key[0] + j, j == 0
+      mt[i] = prev;
+    }
+    mt[0] = prev;  // i wrapped: mt[0] = mt[N-1]
+    prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;    // 624th iteration at i = 1
+    mt[1] = prev;
+    for (int i = 2; i < GE_MT_N; i++) {
+      prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+      mt[i] = prev;
+    }
+    mt[0] = prev;
+    mt[1] = (mt[1] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+    mt[0] = 0x80000000u;
   }
-  mt[0] = prev;  // i wrapped: mt[0] = mt[N-1]
-  prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;    // 624th iteration at i = 1
-  mt[1] = prev;
-  for (int i = 2; i < GE_MT_N; i++) {
-    prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-    mt[i] = prev;
-  }
-  mt[0] = prev;
-  mt[1] = (mt[1] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
-  mt[0] = 0x80000000u;
+  ge_wave_sync();
 }
 
-// np.random.seed(int): init_genrand(s) ([np] mt19937.c). One lane.
-GE_DEV void ge_mt_seed_numpy(uint32_t *mt, uint32_t seed) {
-  uint32_t prev = seed;
-  mt[0] = prev;
-  for (int i = 1; i < GE_MT_N; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; mt[i] = prev; }
+// np.random.seed(int): init_genrand(s) ([np] mt19937.c).  Collective.
+GE_DEV void ge_mt_seed_numpy(uint32_t *mt, uint32_t seed, int lane) {
+  if (lane == 0) {
+    uint32_t prev = seed;
+    mt[0] = prev;
+    for (int i = 1; i < GE_MT_N; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; mt[i] = prev; }
+  }
+  ge_wave_sync();
 }
 
 GE_DEV int ge_wave_incl_scan(int x, int lane) {
@@ -115,7 +122,7 @@ GE_DEV int ge_reach_wave(const GeRctx &c, int ng, int W, int start, const uint64
     uint64_t s = ((start >> 6) == lane) ? (1ull << (start & 63)) : 0ull;
     fr[lane] = s; vis[lane] = s | (removed ? removed[lane] : 0ull);
   }
-  ge_sync();
+  ge_wave_sync();
   for (;;) {
     uint64_t any = 0;
     for (int k = 0; k < W; k++) {
@@ -128,14 +135,14 @@ GE_DEV int ge_reach_wave(const GeRctx &c, int ng, int W, int start, const uint64
       if (lane == 0) nx[k] = b;
       any |= b;
     }
-    ge_sync();
+    ge_wave_sync();
     if (!any) break;
     if (lane < W) { vis[lane] |= nx[lane]; fr[lane] = nx[lane]; }
-    ge_sync();
+    ge_wave_sync();
   }
   int cnt = 0;
   for (int w = 0; w < W; w++) cnt += ge_popc64(vis[w] & ~(removed ? removed[w] : 0ull));
-  ge_sync();
+  ge_wave_sync();
   return cnt;
 }
 
@@ -143,7 +150,7 @@ GE_DEV int ge_reach_wave(const GeRctx &c, int ng, int W, int start, const uint64
 GE_DEV bool ge_connected(const GeRctx &c, int ng, int W, int skip, int lane) {
   uint64_t *rem = c.bits + 3 * W;
   if (lane < W) rem[lane] = (skip >= 0 && (skip >> 6) == lane) ? (1ull << (skip & 63)) : 0ull;
-  ge_sync();
+  ge_wave_sync();
   int start = (skip == 0) ? 1 : 0;
   return ge_reach_wave(c, ng, W, start, rem, lane) == ng - (skip >= 0 ? 1 : 0);
 }
@@ -214,14 +221,13 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   GE_STAMP(0);
   if (mode != GE_RESET_INJECT) {
     // ---------------------------------------------------------------- topology (python stream)
-    if (lane == 0) ge_mt_seed_python(c.mt, seed);
-    ge_sync();
+    ge_mt_seed_python(c.mt, seed, lane);
     GE_STAMP(1);
     int pypos = GE_MT_N;
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
     for (;;) {
       for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
-      ge_sync();
+      ge_wave_sync();
       if (P.complete) {  // [nx] complete_graph: sorted rows
         for (int v = lane; v < ng; v += GE_WAVE)
           for (int w = 0; w < W; w++) {
@@ -282,11 +288,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
             c.elist[cnt + arank] = (uint32_t)u | ((uint32_t)v << 16);
           }
           cnt += nacc; pypos += consumed;
-          ge_sync();
+          ge_wave_sync();
           if (last_round) break;
         }
       }
-      ge_sync();
+      ge_wave_sync();
       bool ok = ge_connected(c, ng, W, -1, lane);
       if (ok && t == GE_TSP) {  // tsp.py:65-71
         uint64_t deg1 = 0;
@@ -304,20 +310,20 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     // ---------------------------------------------------------------- injected topology
     for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
     for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 0;
-    ge_sync();
+    ge_wave_sync();
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = (int)inj.links[(ebase + idx) * 2], v = (int)inj.links[(ebase + idx) * 2 + 1];
       atomicAdd(&c.fill[u], 1);
       atomicOr((unsigned long long *)&c.abits[u * W + (v >> 6)], (unsigned long long)(1ull << (v & 63)));
     }
-    ge_sync();
+    ge_wave_sync();
   }
 
   GE_STAMP(2);
   // ------------------------------------------------------------------ CSR in insertion order
   if (mode != GE_RESET_INJECT) {
     for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
-    ge_sync();
+    ge_wave_sync();
   }
   {
     int carry = 0;
@@ -328,7 +334,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       carry += ge_shfl_i32(incl, GE_WAVE - 1);
     }
     if (lane == 0) c.rowptr[n] = carry;
-    ge_sync();
+    ge_wave_sync();
   }
   if (mode == GE_RESET_INJECT) {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
@@ -336,23 +342,23 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       c.colw[idx] = (uint16_t)((v << 4) | (inj.wcode[ebase + idx] & 15));
       if (!P.complete) c.tmp[idx] = (uint32_t)u;
     }
-    ge_sync();
+    ge_wave_sync();
   } else if (P.complete) {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = idx / (ng - 1), k = idx % (ng - 1);
       int v = k < u ? k : k + 1;
       c.colw[idx] = (uint16_t)((v << 4) | 10);
     }
-    ge_sync();
+    ge_wave_sync();
   } else {
     for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 0;
-    ge_sync();
+    ge_wave_sync();
     for (int id = lane; id < m; id += GE_WAVE) {
       uint32_t e = c.elist[id]; int u = (int)(e & 0xffffu), v = (int)(e >> 16);
       int s = c.rowptr[u] + atomicAdd(&c.fill[u], 1); c.tmp[s] = ((uint32_t)id << 16) | (uint32_t)v;
       int s2 = c.rowptr[v] + atomicAdd(&c.fill[v], 1); c.tmp[s2] = ((uint32_t)id << 16) | (uint32_t)u;
     }
-    ge_sync();
+    ge_wave_sync();
     for (int v = lane; v < n; v += GE_WAVE) {  // order each row by edge id == insertion order
       int lo = c.rowptr[v], hi = c.rowptr[v + 1];
       for (int a = lo + 1; a < hi; a++) {
@@ -361,11 +367,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         c.tmp[b + 1] = key;
       }
     }
-    ge_sync();
+    ge_wave_sync();
     for (int idx = lane; idx < E; idx += GE_WAVE) c.colw[idx] = (uint16_t)(((c.tmp[idx] & 0xffffu) << 4) | 10u);
-    ge_sync();
+    ge_wave_sync();
     for (int v = lane; v < n; v += GE_WAVE) for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) c.tmp[k] = (uint32_t)v;
-    ge_sync();
+    ge_wave_sync();
   }
 
   GE_STAMP(3);
@@ -373,7 +379,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   if (mode != GE_RESET_INJECT) {
     const bool needs_np = (t != GE_DENSEST_SUBGRAPH);
     int nppos = GE_MT_N;
-    if (needs_np) { if (lane == 0) ge_mt_seed_numpy(c.mt, seed); ge_sync(); }
+    if (needs_np) ge_mt_seed_numpy(c.mt, seed, lane);
     GE_STAMP(4);
     int total = 0;  // masked-rejection draws of randint(3, 10); n*n < 2^24
     if (P.weighted) {
@@ -390,11 +396,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         if (fl) c.elist[carry + incl - 1] = (uint32_t)idx;
         carry += ge_shfl_i32(incl, GE_WAVE - 1);
       }
-      ge_sync();
+      ge_wave_sync();
     }
     if (t == GE_MAX_INDEPENDENT_SET) { for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 10; }
     for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
-    ge_sync();
+    ge_wave_sync();
     int base = 0;
     while (base < total) {
       if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
@@ -427,19 +433,19 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         base += nacc;
         nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
       }
-      ge_sync();
+      ge_wave_sync();
     }
     for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
       c.colw[idx] = (uint16_t)((v << 4) | c.wsort[ge_sorted_pos(c, W, u, v)]);
     }
-    ge_sync();
+    ge_wave_sync();
     GE_STAMP(5);
     // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane
     int kterm = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) ? 2 : (t == GE_STEINER_TREE ? P.n_dests + 1 : 0);
     if (kterm) {
       for (int v = lane; v < n; v += GE_WAVE) c.perm[v] = v;
-      ge_sync();
+      ge_wave_sync();
       int i = n - 1;
       for (;;) {
         if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
@@ -453,7 +459,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         }
         nppos = ge_shfl_i32(nppos, 0);
         int ib = ge_shfl_i32(i, 0);
-        ge_sync();
+        ge_wave_sync();
         if (ib < 1) break;
       }
       src = c.perm[0]; dest = c.perm[1];
@@ -463,10 +469,10 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
       c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)(c.colw[idx] & 15);
     }
-    ge_sync();
+    ge_wave_sync();
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) {
       for (int k = lane; k < T; k += GE_WAVE) c.perm[k] = inj.terminals[(int64_t)env * T + k];
-      ge_sync();
+      ge_wave_sync();
       src = c.perm[0]; dest = c.perm[1];
     }
   }
@@ -480,7 +486,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || (t == GE_STEINER_TREE && P.n_dests == 1)) {
       // [nx] dijkstra: least fixpoint of d[u] = min_v fl(d[v] + w(v,u)); Jacobi sweeps in LDS
       for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = (v == src) ? 0.0 : __builtin_inf();
-      ge_sync();
+      ge_wave_sync();
       for (int it = 0; it < n; it++) {
         uint64_t any = 0;
         for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
@@ -495,40 +501,40 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
           }
           any |= ge_ballot(ch);
         }
-        ge_sync();
+        ge_wave_sync();
         for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = c.delta[v];
-        ge_sync();
+        ge_wave_sync();
         if (!any) break;
       }
       double d = c.sigma[dest];
       heuristic = (t == GE_LONGEST_PATH) ? -d : d;
-      ge_sync();
+      ge_wave_sync();
     } else if (t == GE_STEINER_TREE && P.n_dests == n - 1) {
       // steiner_tree.py:80-81 MST total: Prim on integer codes, summed in ascending order
       for (int v = lane; v < n; v += GE_WAVE) c.dist[v] = (v == 0) ? 0 : 255;
       if (lane < 16) c.misc[lane] = 0;
       uint64_t *intree = c.bits;
       if (lane < W) intree[lane] = 0ull;
-      ge_sync();
+      ge_wave_sync();
       for (int it = 0; it < n; it++) {
         uint32_t best = 0xffffffffu;
         for (int v = lane; v < n; v += GE_WAVE)
           if (!((intree[v >> 6] >> (v & 63)) & 1ull)) { uint32_t key = ((uint32_t)c.dist[v] << 16) | (uint32_t)v; if (key < best) best = key; }
         for (int off = 32; off >= 1; off >>= 1) { uint32_t o = ge_shfl_u32(best, lane ^ off); if (o < best) best = o; }
         int pick = (int)(best & 0xffffu), code = (int)(best >> 16);
-        ge_sync();
+        ge_wave_sync();
         if (lane == 0) { intree[pick >> 6] |= 1ull << (pick & 63); if (it) c.misc[code & 15]++; }
-        ge_sync();
+        ge_wave_sync();
         for (int k = c.rowptr[pick] + lane; k < c.rowptr[pick + 1]; k += GE_WAVE) {
           int u = c.colw[k] >> 4, cd = c.colw[k] & 15;
           if (!((intree[u >> 6] >> (u & 63)) & 1ull) && cd < c.dist[u]) c.dist[u] = cd;
         }
-        ge_sync();
+        ge_wave_sync();
       }
       double s = 0.0;
       for (int code = 3; code <= 10; code++) for (int r = 0; r < c.misc[code]; r++) s += ge_wlut(code);
       heuristic = s;
-      ge_sync();
+      ge_wave_sync();
     } else if (t == GE_DENSEST_SUBGRAPH) heuristic = -1.0;             // densest_subgraph.py:85-88
     else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : kNaN;  // greedy MIS not built
     else heuristic = kNaN;                                              // Kou / Christofides not built
@@ -545,7 +551,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     else if (t == GE_STEINER_TREE) for (int k = 1; k <= P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
     tbits[lane] = tb;
   }
-  ge_sync();
+  ge_wave_sync();
   if (mode == GE_RESET_INJECT) {
     for (int idx = lane; idx < n * F; idx += GE_WAVE) G.x[nbase * F + idx] = inj.x[nbase * F + idx];
   } else {  // flag columns only; the five structural columns are written by the features kernel
@@ -587,29 +593,29 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   const bool node_started = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
   uint64_t *prune = c.bits + 4 * W;  // parenting >= 2: nodes that stay selectable
   if (lane < W) prune[lane] = ~0ull;
-  ge_sync();
+  ge_wave_sync();
   if (t == GE_LONGEST_PATH && P.parenting >= 2) {  // longest_path.py:134-143: has_path(alt_G, k, dest), alt_G = G - src
     uint64_t *rem = c.bits + 5 * W;
     if (lane < W) rem[lane] = ((src >> 6) == lane) ? (1ull << (src & 63)) : 0ull;
-    ge_sync();
+    ge_wave_sync();
     ge_reach_wave(c, n, W, dest, rem, lane);
     if (lane < W) {
       uint64_t keep = c.bits[W + lane] & ~rem[lane];
       if (P.parenting == 3 && n - 1 <= n / 3) keep = ~rem[lane];  // never true for n >= 2; kept for fidelity
       prune[lane] = keep;
     }
-    ge_sync();
+    ge_wave_sync();
   } else if (t == GE_TSP && P.parenting >= 2) {  // tsp.py:181-194: drop v if alt_G - v is disconnected, alt_G = G - start
     uint64_t *rem = c.bits + 5 * W;
     for (int v = 1; v < n; v++) {
       if (!((c.abits[0 * W + (v >> 6)] >> (v & 63)) & 1ull)) continue;  // uniform: candidates are N(start)
       if (n - 2 == 0) break;
       if (lane < W) rem[lane] = (lane == 0 ? 1ull : 0ull) | (((v >> 6) == lane) ? (1ull << (v & 63)) : 0ull);
-      ge_sync();
+      ge_wave_sync();
       int from = (v == 1) ? 2 : 1;
       int reached = ge_reach_wave(c, n, W, from, rem, lane);
       if (reached != n - 2 && lane == (v >> 6)) prune[lane] &= ~(1ull << (v & 63));
-      ge_sync();
+      ge_wave_sync();
     }
   }
   for (int w = lane; w < AW; w += GE_WAVE) {
@@ -625,7 +631,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     G.mask_bits[(int64_t)env * AW + w] = mb;
     ((uint64_t *)c.sigma)[w] = mb;  // staged for the byte expansion below (sigma is free now)
   }
-  ge_sync();
+  ge_wave_sync();
   for (int idx = lane; idx < A; idx += GE_WAVE) G.mask[(int64_t)env * A + idx] = (uint8_t)((((uint64_t *)c.sigma)[idx >> 6] >> (idx & 63)) & 1ull);
   for (int w = lane; w < W; w += GE_WAVE) {
     uint64_t nb = 0;
@@ -640,7 +646,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     G.status[env] = 0; G.heuristic[env] = heuristic;
     if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
   }
-  ge_sync();
+  ge_wave_sync();
   GE_STAMP(10);
 }
 

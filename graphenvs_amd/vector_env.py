@@ -270,6 +270,22 @@ class VectorGraphEnv:
                                                      C.byref(a), C.byref(b), C.byref(c)), "ge_timed_rollout")
         return dict(step_ms=a.value, reset_ms=b.value, policy_ms=c.value)
 
+    def timed_step_burst_raw_ms(self, k, policy_seed=0):
+        """elapsed ms between one pair of HIP events around k back-to-back (sample+)step launches (k = 0: the bare
+        event pair, i.e. the measurement overhead)."""
+        ms = C.c_double()
+        _lib.check(self._L, self._L.ge_timed_step_burst(self._h, int(policy_seed), int(k), self._actions_scratch.data_ptr(),
+                                                        self._stream(), C.byref(ms)), "ge_timed_step_burst")
+        return ms.value
+
+    def timed_step_burst(self, k, policy_seed=0):
+        """k back-to-back (sample+)step launches between one pair of HIP events, no autoreset in between; returns
+        the average launch duration in microseconds."""
+        ms = C.c_double()
+        _lib.check(self._L, self._L.ge_timed_step_burst(self._h, int(policy_seed), int(k), self._actions_scratch.data_ptr(),
+                                                        self._stream(), C.byref(ms)), "ge_timed_step_burst")
+        return ms.value * 1e3 / k
+
     def inject_state(self, links, wcode, x, terminals=None):
         """Parity path: load post-reset states produced elsewhere (links [B,E,2] local ids, wcode [B,E] in
         {3..10}, x [B,n,F], terminals [B,T])."""

@@ -163,6 +163,12 @@ int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64
 int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *actions_scratch,
                      void *stream, double *step_ms_sum, double *reset_ms_sum, double *policy_ms_sum);
 
+/* k back-to-back launches of the (sample +) step kernel between ONE pair of hipEvents, without the autoreset
+ * kernels in between (finished slots simply stop moving): the event overhead is amortised over k launches.
+ * Returns the elapsed milliseconds of the k launches (synchronises; profiling only). */
+int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k, int64_t *actions_scratch, void *stream,
+                        double *burst_ms);
+
 const char *ge_last_error(void);
 
 #ifdef __cplusplus

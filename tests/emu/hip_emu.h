@@ -178,6 +178,7 @@ GE_DEV double ge_shfl_f64(double v, int src) { uint64_t u; memcpy(&u, &v, 8); u 
 
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 GE_DEV void ge_lds_add_f64(double *p, double v) { *p += v; }
+GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return v; }
 GE_DEV int ge_popc64(uint64_t v) { return __builtin_popcountll(v); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
