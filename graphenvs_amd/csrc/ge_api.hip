@@ -65,6 +65,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   P.complete = (m >= max_edges) ? 1 : 0;
   P.n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;  // densest_subgraph.py:38-39
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
+  P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 128) ? 1 : 0;
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
@@ -145,7 +146,7 @@ static int check_launch(const char *what) {
 
 static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, void *stream) {
   int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  GE_LAUNCH(ge_k_reset, grid, GE_WAVE, e->lds_bytes, stream, e->P, seeds, mode, inj);
+  GE_LAUNCH(ge_k_reset, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj);
   int rc = check_launch("reset kernel");
   if (rc != GE_OK || mode == GE_RESET_INJECT) return rc;
   int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);

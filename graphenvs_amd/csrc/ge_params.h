@@ -8,10 +8,16 @@
 #define GE_MT_N 624
 #define GE_MT_M 397
 #define GE_STEP_BLOCK 256
+#define GE_RESET_THREADS 128
+#ifndef GE_RESET_WAVES_PER_SIMD
+#define GE_RESET_WAVES_PER_SIMD 6  // 24 waves / CU = 12 two-wave workgroups: one round for the ~2 700 resets of a headline step
+#endif
 
 // byte offsets into the dynamic LDS of one reset workgroup (one env resident per workgroup)
 struct GeLds {
-  int mt;       // u32[624]  MT19937 state (python stream, then numpy stream)
+  int mt;       // u32[624]  MT19937 state of the python stream (wave 0)
+  int mt2;      // u32[624]  MT19937 state of the numpy stream (wave 1)
+  int wm;       // numpy wave output: nibble matrix u32[n*n/8] of delay codes, or a byte list of m / n codes
   int abits;    // u64[n*W]  adjacency bit rows
   int elist;    // u32[m]    accepted edges in insertion order (u | v << 16); later G.edges order map
   int fill;     // i32[n]    per-row fill counters / degrees
@@ -36,6 +42,7 @@ struct GeLdsF {
 struct GeParams {
   int32_t env_type, B, n, m, E, W, F, Fe, A, AW, T, ng, nflag;
   int32_t weighted, parenting, n_dests, is_eval, autoreset, complete;
+  int32_t np_early;  // the numpy wave can produce every weight code without the topology (dense delay matrix fits LDS)
   double n_choices;
   int64_t env_index_base, seed_stride;
   ge_buffers buf;
@@ -50,6 +57,8 @@ static inline void ge_make_lds(GeParams &P) {
   int o = 0;
   auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
   L.mt = take(GE_MT_N * 4);
+  L.mt2 = take(GE_MT_N * 4);
+  { int nb = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 16; if (P.m > nb) nb = P.m; if (P.n > nb) nb = P.n; L.wm = take(nb); }
   L.abits = take(P.n * P.W * 8);
   L.elist = take((P.m > 0 ? P.m : 1) * 4);
   L.fill = take(P.n * 4);

@@ -12,6 +12,7 @@
 #define GE_DEV static __device__ __forceinline__
 #define GE_DEVFN __device__
 #define GE_KERNEL __global__ void
+#define GE_KERNEL_LB(threads, waves_per_simd) __global__ void __launch_bounds__(threads, waves_per_simd)
 #define GE_HOSTDEV __host__ __device__ inline
 
 GE_DEV int ge_tid() { return (int)threadIdx.x; }

@@ -93,7 +93,7 @@ GE_DEV uint32_t ge_mask_below(uint32_t v) {  // smallest 2^k - 1 >= v
 }
 
 struct GeRctx {
-  uint32_t *mt; uint64_t *abits; uint32_t *elist; int *fill; int *rowptr; uint16_t *colw; uint8_t *wsort;
+  uint32_t *mt, *mt2, *wm; uint64_t *abits; uint32_t *elist; int *fill; int *rowptr; uint16_t *colw; uint8_t *wsort;
   uint32_t *tmp; int *dist; int *perm;
   double *sigma, *delta;
   uint64_t *bits; int *misc;
@@ -103,7 +103,7 @@ GE_DEV GeRctx ge_carve(const GeParams &P) {
   unsigned char *s = ge_dyn_smem();
   const GeLds &L = P.lds;
   GeRctx c;
-  c.mt = (uint32_t *)(s + L.mt); c.abits = (uint64_t *)(s + L.abits); c.elist = (uint32_t *)(s + L.elist);
+  c.mt = (uint32_t *)(s + L.mt); c.mt2 = (uint32_t *)(s + L.mt2); c.wm = (uint32_t *)(s + L.wm); c.abits = (uint64_t *)(s + L.abits); c.elist = (uint32_t *)(s + L.elist);
   c.fill = (int *)(s + L.fill); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
   c.wsort = (uint8_t *)(s + L.wsort); c.tmp = (uint32_t *)(s + L.tmp); c.dist = (int *)(s + L.dist);
   c.perm = (int *)(s + L.perm);
@@ -210,13 +210,103 @@ __device__ unsigned long long ge_stamp_buf[32];
 
 struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; };
 
+
+// masked-rejection draws of randint(3, 10) ([np] buffered_bounded_masked_uint32), 64 per round: draw k of the
+// accepted sequence gets code 3 + value.  sink 0: nibble matrix wm[k] (k = i*n + j of the delay matrix);
+// sink 1: byte list wm[k]; sink 2: delay[i, j] lands by rank in wsort (needs the topology).  One wave.
+GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int total, int lane, int sink) {
+  const int n = P.n, W = P.W;
+  int base = 0;
+  while (base < total) {
+    if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+    int p = nppos + lane; bool valid = p < GE_MT_N;
+    uint32_t val = valid ? (ge_temper(mt[p]) & 7u) : 8u;
+    bool acc = valid && val <= 6u;
+    uint64_t bal = ge_ballot(acc);
+    int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
+    int idx = base + rank;
+    if (acc && idx < total) {
+      uint32_t code = 3u + val;
+      if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
+      else if (sink == 1) ((uint8_t *)c.wm)[idx] = (uint8_t)code;
+      else {
+        int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
+        if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
+          c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
+        }
+      }
+    }
+    int nacc = ge_popc64(bal);
+    if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
+      int need = total - base - 1;
+      uint64_t lastb = ge_ballot(acc && rank == need);
+      nppos += ge_ctz64(lastb) + 1;
+      base = total;
+    } else {
+      base += nacc;
+      nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+    }
+    ge_wave_sync();
+  }
+}
+
+// np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane; result in c.perm
+GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
+  const int n = P.n;
+  for (int v = lane; v < n; v += GE_WAVE) c.perm[v] = v;
+  ge_wave_sync();
+  int i = n - 1;
+  for (;;) {
+    if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+    if (lane == 0) {
+      while (i >= 1 && nppos < GE_MT_N) {
+        uint32_t j = ge_temper(mt[nppos++]) & ge_mask_below((uint32_t)i);
+        if (j > (uint32_t)i) continue;
+        int tv = c.perm[i]; c.perm[i] = c.perm[(int)j]; c.perm[(int)j] = tv;
+        i--;
+      }
+    }
+    nppos = ge_shfl_i32(nppos, 0);
+    int ib = ge_shfl_i32(i, 0);
+    ge_wave_sync();
+    if (ib < 1) break;
+  }
+}
+
+// The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
+// depend on the topology runs beside the python-stream graph sampling of the first wave.
+GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, uint32_t seed, int lane) {
+  const int t = P.env_type, n = P.n;
+  if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
+  ge_mt_seed_numpy(c.mt2, seed, lane);
+  if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
+  int nppos = GE_MT_N;
+  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+  if (P.weighted) {
+    if (path_like) {
+      for (int i = lane; i < (n * n + 7) / 8; i += GE_WAVE) c.wm[i] = 0u;
+      ge_wave_sync();
+      ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 0);
+    } else ge_np_draws(P, c, c.mt2, nppos, t == GE_TSP ? P.m : n, lane, 1);
+  }
+  if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane);
+}
+
 GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
-  const int lane = ge_tid();
+  // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
+  // Inside a wave only wave-level hand-offs are used; the two block barriers are the join and the end of the slot.
+  const int lane = ge_tid() & (GE_WAVE - 1);
+  const int wv = ge_tid() >> 6;
   const int n = P.n, ng = P.ng, W = P.W, m = P.m, E = P.E, F = P.F, T = P.T;
   const int t = P.env_type;
   GeRctx c = ge_carve(P);
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   int src = 0, dest = -1;
+  if (wv == 1) {
+    if (mode != GE_RESET_INJECT) { ge_numpy_wave(P, c, seed, lane); ge_sync(); }
+    ge_sync();
+    return;
+  }
 
   GE_STAMP(0);
   if (mode != GE_RESET_INJECT) {
@@ -320,6 +410,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
 
   GE_STAMP(2);
+  if (mode != GE_RESET_INJECT) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
   // ------------------------------------------------------------------ CSR in insertion order
   if (mode != GE_RESET_INJECT) {
     for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
@@ -375,95 +466,45 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
 
   GE_STAMP(3);
-  // ------------------------------------------------------------------ weights + terminals (numpy stream)
+  // ------------------------------------------------------------------ weight codes + terminals
   if (mode != GE_RESET_INJECT) {
-    const bool needs_np = (t != GE_DENSEST_SUBGRAPH);
-    int nppos = GE_MT_N;
-    if (needs_np) ge_mt_seed_numpy(c.mt, seed, lane);
-    GE_STAMP(4);
-    int total = 0;  // masked-rejection draws of randint(3, 10); n*n < 2^24
-    if (P.weighted) {
-      if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) total = n * n;
-      else if (t == GE_TSP) total = m;
-      else if (t == GE_MAX_INDEPENDENT_SET) total = n;
-    }
-    if (t == GE_TSP && P.weighted) {  // G.edges order: u ascending, insertion order, v > u (tsp.py:88-90)
+    for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
+    ge_wave_sync();
+    const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+    if (P.weighted && path_like && P.np_early) {  // delay[u, v], u < v, from the nibble matrix the numpy wave filled
+      for (int idx = lane; idx < E; idx += GE_WAVE) {
+        int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+        int a = u < v ? u : v, b = u < v ? v : u, cell = a * n + b;
+        c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u);
+      }
+    } else if (P.weighted && t == GE_TSP) {  // k-th edge of G.edges (u ascending, insertion order, v > u) gets draw k
       int carry = 0;
       for (int k0 = 0; k0 < E; k0 += GE_WAVE) {
         int idx = k0 + lane; int fl = 0;
         if (idx < E) fl = ((int)(c.colw[idx] >> 4) > ge_row_of(P, c, idx)) ? 1 : 0;
         int incl = ge_wave_incl_scan(fl, lane);
-        if (fl) c.elist[carry + incl - 1] = (uint32_t)idx;
+        if (fl) {
+          int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+          uint8_t code = ((const uint8_t *)c.wm)[carry + incl - 1];
+          c.wsort[ge_sorted_pos(c, W, u, v)] = code; c.wsort[ge_sorted_pos(c, W, v, u)] = code;
+        }
         carry += ge_shfl_i32(incl, GE_WAVE - 1);
       }
-      ge_wave_sync();
+    } else if (t == GE_MAX_INDEPENDENT_SET) {
+      for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = P.weighted ? (int)((const uint8_t *)c.wm)[v] : 10;
+    } else if (P.weighted && path_like) {  // n too large for the dense matrix: draw now, codes land by rank
+      int nppos = GE_MT_N;
+      ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 2);
+      ge_np_terminals(P, c, c.mt2, nppos, lane);
     }
-    if (t == GE_MAX_INDEPENDENT_SET) { for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = 10; }
-    for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
     ge_wave_sync();
-    int base = 0;
-    while (base < total) {
-      if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
-      int p = nppos + lane; bool valid = p < GE_MT_N;
-      uint32_t val = valid ? (ge_temper(c.mt[p]) & 7u) : 8u;
-      bool acc = valid && val <= 6u;
-      uint64_t bal = ge_ballot(acc);
-      int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
-      int idx = base + rank;
-      if (acc && idx < total) {
-        int code = 3 + (int)val;
-        if (t == GE_MAX_INDEPENDENT_SET) c.fill[idx] = code;
-        else if (t == GE_TSP) {
-          int k = (int)c.elist[idx]; int u = ge_row_of(P, c, k), v = (int)(c.colw[k] >> 4);
-          c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, v, u)] = (uint8_t)code;
-        } else {
-          int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
-          if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
-            c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
-          }
-        }
-      }
-      int nacc = ge_popc64(bal);
-      if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
-        int need = total - base - 1;
-        uint64_t lastb = ge_ballot(acc && rank == need);
-        nppos += ge_ctz64(lastb) + 1;
-        base = total;
-      } else {
-        base += nacc;
-        nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
-      }
-      ge_wave_sync();
-    }
     for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
       c.colw[idx] = (uint16_t)((v << 4) | c.wsort[ge_sorted_pos(c, W, u, v)]);
     }
     ge_wave_sync();
     GE_STAMP(5);
-    // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane
-    int kterm = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) ? 2 : (t == GE_STEINER_TREE ? P.n_dests + 1 : 0);
-    if (kterm) {
-      for (int v = lane; v < n; v += GE_WAVE) c.perm[v] = v;
-      ge_wave_sync();
-      int i = n - 1;
-      for (;;) {
-        if (nppos >= GE_MT_N) { ge_mt_twist(c.mt, lane); nppos = 0; }
-        if (lane == 0) {
-          while (i >= 1 && nppos < GE_MT_N) {
-            uint32_t j = ge_temper(c.mt[nppos++]) & ge_mask_below((uint32_t)i);
-            if (j > (uint32_t)i) continue;
-            int tv = c.perm[i]; c.perm[i] = c.perm[(int)j]; c.perm[(int)j] = tv;
-            i--;
-          }
-        }
-        nppos = ge_shfl_i32(nppos, 0);
-        int ib = ge_shfl_i32(i, 0);
-        ge_wave_sync();
-        if (ib < 1) break;
-      }
-      src = c.perm[0]; dest = c.perm[1];
-    }
+    if (path_like) { src = c.perm[0]; dest = c.perm[1]; }
   } else {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
@@ -646,7 +687,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     G.status[env] = 0; G.heuristic[env] = heuristic;
     if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
   }
-  ge_wave_sync();
+  ge_sync();
   GE_STAMP(10);
 }
 
@@ -675,10 +716,15 @@ GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
   return P.buf.reset_list[lo * GE_STEP_BLOCK + (q - pre[lo])];
 }
 
-GE_KERNEL ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj) {
+GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
-  int count = (mode == GE_RESET_QUEUE) ? ge_queue_prefix(P, pre, ge_tid()) : P.B;
+  int count = P.B;
+  if (mode == GE_RESET_QUEUE) {
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    ge_sync();
+    count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
+  }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
     int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
     uint32_t seed = (mode == GE_RESET_ALL) ? seeds[env] : ((mode == GE_RESET_QUEUE) ? P.buf.seed[env] : 0u);

@@ -23,6 +23,7 @@
 #define GE_DEV static inline
 #define GE_DEVFN inline
 #define GE_KERNEL static void
+#define GE_KERNEL_LB(threads, waves_per_simd) static void
 #define GE_HOSTDEV inline
 
 // ---- minimal HIP runtime surface used by ge_api
