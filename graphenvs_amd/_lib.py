@@ -30,7 +30,8 @@ class GeConfig(C.Structure):
         ("env_type", C.c_int32), ("num_envs", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
         ("weighted", C.c_int32), ("parenting", C.c_int32), ("n_dests", C.c_int32), ("spatial", C.c_int32),
         ("is_eval_env", C.c_int32), ("autoreset", C.c_int32), ("n_choices", C.c_double),
-        ("env_index_base", C.c_int64), ("seed_stride", C.c_int64),
+        ("env_index_base", C.c_int64), ("seed_stride", C.c_int64), ("node_id_base", C.c_int64),
+        ("edge_row_stride", C.c_int64),
     ]
 
 
@@ -43,7 +44,7 @@ class GeLayout(C.Structure):
 
 
 BUFFER_FIELDS = [
-    "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "adj_bits", "node_rec", "rev_edge", "head", "cur_rec", "terminals",
+    "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "head", "cur_rec", "terminals",
     "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
     "final_len", "reset_list", "reset_count", "work_list", "work_count",

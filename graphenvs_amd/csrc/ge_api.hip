@@ -50,7 +50,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (t == GE_TSP && cfg->spatial && !cfg->weighted) return fail(GE_E_BADARG, "Spatial TSP must be weighted (tsp.py:27)");
   if (t == GE_STEINER_TREE && (cfg->n_dests < 1 || cfg->n_dests > n - 1)) return fail(GE_E_BADARG, "n_dests must be in [1, n_nodes-1]");
   // not built yet
-  if (t == GE_TSP && cfg->spatial) return fail(GE_E_UNSUPPORTED, "spatial TSP is not built yet");
+  if (t == GE_TSP && cfg->spatial && n > 512) return fail(GE_E_UNSUPPORTED, "spatial TSP is built for n_nodes <= 512");
   if ((t == GE_LONGEST_PATH || t == GE_TSP) && cfg->parenting >= 2 && n > 64 * GE_MAXW) return fail(GE_E_UNSUPPORTED, "parenting >= 2 is built for n_nodes <= 512");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
@@ -61,10 +61,13 @@ static int derive(const ge_config *cfg, GeParams &P) {
   P.AW = (P.A + 63) / 64;
   P.T = (t == GE_STEINER_TREE) ? (cfg->n_dests + 1 > 2 ? cfg->n_dests + 1 : 2) : 2;
   P.weighted = cfg->weighted ? 1 : 0; P.parenting = cfg->parenting; P.n_dests = cfg->n_dests;
+  P.spatial = (t == GE_TSP && cfg->spatial) ? 1 : 0;
   P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset ? 1 : 0;
   P.complete = (m >= max_edges) ? 1 : 0;
   P.n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;  // densest_subgraph.py:38-39
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
+  P.node_id_base = cfg->node_id_base;
+  P.edge_row_stride = cfg->edge_row_stride > 0 ? cfg->edge_row_stride : (int64_t)cfg->num_envs * 2 * m;
   P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 128) ? 1 : 0;
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
@@ -99,6 +102,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
                         bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
+  if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
   if (P.W == 1 && (!bufs->node_rec || !bufs->cur_rec)) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec and cur_rec");
   P.buf = *bufs;
   ge_engine *e = new (std::nothrow) ge_engine();
@@ -114,7 +118,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
     if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  e->feat_fast = (P.n <= 64) ? 1 : 0;
+  e->feat_fast = (P.n <= 64 && !P.spatial) ? 1 : 0;  // float64 weights do not fit the fast path's LDS
   e->feat_lds = e->feat_fast ? ge_f64_bytes(P.E, P.env_type == GE_TSP, nblk) : P.ldsf.total;
   if (e->feat_lds > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "feature kernel does not fit LDS"); }
   if (P.ldsf.total > 64 * 1024) {

@@ -101,7 +101,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
     int i = k0 + lane; bool dang = false;
     if (i < n) {
       double S = 0.0;
-      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? ge_wlut(c.scw[k] & 15) : 1.0) * 1.0;
+      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : ge_wlut(c.scw[k] & 15)) : 1.0) * 1.0;
       c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
       c.prx[i] = pinit;
       dang = (c.rowptr[i + 1] == c.rowptr[i]);
@@ -118,7 +118,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
       double acc = 0.0;
       for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
         int j = c.scw[k] >> 4;
-        double dat = c.sinv[j] * (prw ? ge_wlut(c.scw[k] & 15) : 1.0);
+        double dat = c.sinv[j] * (prw ? (P.spatial ? G.sw64[ebase + k] : ge_wlut(c.scw[k] & 15)) : 1.0);
         acc += dat * c.prx[j];
       }
       double xn = alpha * (acc + dsum * pinit) + oma * pinit;

@@ -42,9 +42,10 @@ struct GeLdsF {
 struct GeParams {
   int32_t env_type, B, n, m, E, W, F, Fe, A, AW, T, ng, nflag;
   int32_t weighted, parenting, n_dests, is_eval, autoreset, complete;
+  int32_t spatial;   // TSP with coordinates and float64 Euclidean weights (sw64 slab)
   int32_t np_early;  // the numpy wave can produce every weight code without the topology (dense delay matrix fits LDS)
   double n_choices;
-  int64_t env_index_base, seed_stride;
+  int64_t env_index_base, seed_stride, node_id_base, edge_row_stride;
   ge_buffers buf;
   GeLds lds;
   GeLdsF ldsf;
@@ -58,7 +59,9 @@ static inline void ge_make_lds(GeParams &P) {
   auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
   L.mt = take(GE_MT_N * 4);
   L.mt2 = take(GE_MT_N * 4);
-  { int nb = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 16; if (P.m > nb) nb = P.m; if (P.n > nb) nb = P.n; L.wm = take(nb); }
+  { int nb = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 16; if (P.m > nb) nb = P.m; if (P.n > nb) nb = P.n;
+    if (P.spatial && 32 * P.n > nb) nb = 32 * P.n;  // raw draws u32[4n] + coordinates f64[2n]
+    L.wm = take(nb); }
   L.abits = take(P.n * P.W * 8);
   L.elist = take((P.m > 0 ? P.m : 1) * 4);
   L.fill = take(P.n * 4);

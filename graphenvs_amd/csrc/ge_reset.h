@@ -282,7 +282,23 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, uint32_t seed, int
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
   const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
-  if (P.weighted) {
+  if (P.spatial) {  // tsp.py:81-83: x, y = np.random.rand() * 10 per node; rand() = two 32-bit draws, no rejection
+    uint32_t *raw = c.wm; double *xy = (double *)(c.wm + 4 * n);
+    for (int p0 = 0; p0 < 4 * n; p0 += GE_WAVE) {
+      if (nppos >= GE_MT_N) { ge_mt_twist(c.mt2, lane); nppos = 0; }
+      int p = nppos + lane; bool valid = p < GE_MT_N && p0 + lane < 4 * n;
+      if (valid) raw[p0 + lane] = ge_temper(c.mt2[p]);
+      int adv = (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+      if (p0 + adv > 4 * n) adv = 4 * n - p0;
+      nppos += adv; p0 += adv - GE_WAVE;  // a short block (state boundary) advances by what it delivered
+      ge_wave_sync();
+    }
+    for (int k = lane; k < 2 * n; k += GE_WAVE) {  // [np] mt19937_next_double: (a >> 5, b >> 6) -> 53 bits
+      int32_t a = (int32_t)(raw[2 * k] >> 5), b = (int32_t)(raw[2 * k + 1] >> 6);
+      xy[k] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0 * 10;
+    }
+    ge_wave_sync();
+  } else if (P.weighted) {
     if (path_like) {
       for (int i = lane; i < (n * n + 7) / 8; i += GE_WAVE) c.wm[i] = 0u;
       ge_wave_sync();
@@ -477,6 +493,14 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         int a = u < v ? u : v, b = u < v ? v : u, cell = a * n + b;
         c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u);
       }
+    } else if (P.spatial) {  // tsp.py:85-86: Euclidean distance, float64, stored in ascending-neighbour order
+      const double *xy = (const double *)(c.wm + 4 * n);
+      for (int idx = lane; idx < E; idx += GE_WAVE) {
+        int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+        int a = u < v ? u : v, b = u < v ? v : u;  // G.edges yields (min, max)
+        double dx = xy[2 * a] - xy[2 * b], dy = xy[2 * a + 1] - xy[2 * b + 1];
+        P.buf.sw64[ebase + ge_sorted_pos(c, W, u, v)] = __builtin_sqrt(dx * dx + dy * dy);
+      }
     } else if (P.weighted && t == GE_TSP) {  // k-th edge of G.edges (u ascending, insertion order, v > u) gets draw k
       int carry = 0;
       for (int k0 = 0; k0 < E; k0 += GE_WAVE) {
@@ -584,7 +608,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   GE_STAMP(9);
   // ------------------------------------------------------------------ write the slot to HBM
   const ge_buffers &G = P.buf;
-  const int64_t Ne = (int64_t)P.B * E;
+  const int64_t Ne = P.edge_row_stride;
   uint64_t *tbits = c.bits + 3 * W;  // target set
   if (lane < W) {
     uint64_t tb = 0;
@@ -602,16 +626,17 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       bool is_t = (tbits[v >> 6] >> (v & 63)) & 1ull;
       if (t == GE_SHORTEST_PATH || t == GE_STEINER_TREE) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : 0.f);
       else if (t == GE_LONGEST_PATH) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : ((P.parenting == 0 && v == src) ? 2.f : 0.f));
-      else if (t == GE_TSP) val = (col == 1 && v == 0) ? 1.f : 0.f;
+      else if (t == GE_TSP) val = (col == 1 && v == 0) ? 1.f : ((P.spatial && col >= 2) ? (float)((const double *)(c.wm + 4 * n))[2 * v + (col - 2)] : 0.f);
       else if (t == GE_MAX_INDEPENDENT_SET) val = (col == 0) ? (float)ge_wlut(c.fill[v]) : 0.f;
       G.x[(nbase + v) * F + col] = val;
     }
   }
   for (int idx = lane; idx < E; idx += GE_WAVE) {
     int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4, code = c.colw[idx] & 15;
-    G.edge_index[ebase + idx] = nbase + u;
-    G.edge_index[Ne + ebase + idx] = nbase + v;
+    G.edge_index[ebase + idx] = P.node_id_base + nbase + u;
+    G.edge_index[Ne + ebase + idx] = P.node_id_base + nbase + v;
     float wv = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 1.f : (float)ge_wlut(code);
+    if (P.spatial) wv = (float)G.sw64[ebase + ge_sorted_pos(c, W, u, v)];
     if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
     else G.edge_attr[ebase + idx] = wv;
     G.colw[ebase + idx] = c.colw[idx];

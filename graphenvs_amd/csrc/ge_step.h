@@ -135,6 +135,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
           acted = true;
           int code = ge_edge_code(P, i, head, a);
           double wgt = ge_wlut(code);
+          if (P.spatial) wgt = G.sw64[(int64_t)i * P.E + G.row_ptr[(int64_t)i * (n + 1) + head] + ge_rank_below(G.adj_bits + (nbase + head) * W, a)];
           reward = 0.0 - wgt;
           G.cost[i] = G.cost[i] + wgt;
           G.x[(nbase + a) * F + 0] = 1.f;
@@ -483,12 +484,12 @@ GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
 GE_KERNEL ge_k_vectorize(GeParams P, float *out) {
   const int64_t L = (int64_t)P.n * P.F + (int64_t)P.E * P.Fe + 2 * (int64_t)P.E;
   const int64_t p1 = (int64_t)P.n * P.F, p2 = p1 + (int64_t)P.E * P.Fe;
-  const int64_t total = (int64_t)P.B * L, Ne = (int64_t)P.B * P.E;
+  const int64_t total = (int64_t)P.B * L, Ne = P.edge_row_stride;
   for (int64_t idx = (int64_t)ge_bid() * ge_bdim() + ge_tid(); idx < total; idx += (int64_t)ge_gdim() * ge_bdim()) {
     int64_t b = idx / L, j = idx % L; float v;
     if (j < p1) v = P.buf.x[b * p1 + j];
     else if (j < p2) v = P.buf.edge_attr[b * (int64_t)P.E * P.Fe + (j - p1)];
-    else { int64_t q = j - p2, e = q >> 1; v = (float)(P.buf.edge_index[(q & 1) * Ne + b * P.E + e] - b * P.n); }
+    else { int64_t q = j - p2, e = q >> 1; v = (float)(P.buf.edge_index[(q & 1) * Ne + b * P.E + e] - b * P.n - P.node_id_base); }
     out[idx] = v;
   }
 }

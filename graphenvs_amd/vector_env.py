@@ -81,7 +81,8 @@ class VectorGraphEnv:
     """B independent envs of one id on one GPU.  One instance per process/GPU; no global state."""
 
     def __init__(self, env_id, num_envs, n_nodes, n_edges, device="cuda", autoreset=True, obs_mode="pyg",
-                 env_index_base=0, seed_stride=None, strict=False, _library=None, **kwargs):
+                 env_index_base=0, seed_stride=None, strict=False, _library=None, _views=None, node_id_base=0,
+                 edge_row_stride=0, **kwargs):
         self.env_id = env_id
         self.kwargs = normalize_kwargs(env_id, n_nodes, n_edges, **kwargs)
         self.num_envs = int(num_envs)
@@ -105,7 +106,7 @@ class VectorGraphEnv:
             _lib.ENV_TYPES[env_id], self.num_envs, self.n, self.m, int(bool(kw.get("weighted", False))),
             int(kw.get("parenting", -1)), int(kw.get("n_dests", 0)), int(bool(kw.get("spatial", False))),
             int(bool(kw.get("is_eval_env", False))), int(self.autoreset), float(kw.get("n_choices", -1)),
-            self.env_index_base, self.seed_stride)
+            self.env_index_base, self.seed_stride, int(node_id_base), int(edge_row_stride))
         lay = _lib.GeLayout()
         _lib.check(self._L, self._L.ge_get_layout(C.byref(self.cfg), C.byref(lay)), "ge_get_layout")
         self.layout = lay
@@ -123,6 +124,7 @@ class VectorGraphEnv:
         t["row_ptr"] = z((B, n + 1), torch.int32)
         t["colw"] = z((B * E,), torch.int16)
         t["scode"] = z((B * E,), torch.uint8)
+        t["sw64"] = z((B * E,), torch.float64) if kw.get("spatial", False) else None
         t["adj_bits"] = z((B * n, W), torch.int64)
         t["node_rec"] = z((B * n, 2), torch.int64) if W == 1 else None
         t["rev_edge"] = z((B * E,), torch.int32) if env_id == "SteinerTree-v0" else None
@@ -151,6 +153,11 @@ class VectorGraphEnv:
         t["reset_count"] = z(((B + 255) // 256,), torch.int32)
         t["work_list"] = z((B,), torch.int32)
         t["work_count"] = z((4,), torch.int32)
+        if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
+            for k, v in _views.items():
+                assert v.dtype == t[k].dtype and v.numel() >= (t[k].numel() if k != "edge_index" else 0), k
+                t[k] = v
+        self.node_id_base = int(node_id_base)
         self.t = t
         bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in t.items()})
         h = C.c_void_p()
@@ -158,7 +165,7 @@ class VectorGraphEnv:
         self._h = h
         # static parts of the PyG view
         self._batch = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(n)
-        self._ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n
+        self._ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n + int(node_id_base)
         self._truncated = torch.zeros(B, dtype=torch.bool, device=dev)
         self._actions_scratch = z((B,), torch.int64)
         self._flat = None
@@ -315,8 +322,9 @@ class VectorGraphEnv:
 
     def edge_links(self):
         """[B, E, 2] local node ids (GraphInstance.edge_links of every slot)."""
+        assert self.cfg.edge_row_stride in (0, self.num_envs * self.E), "use RaggedVectorEnv.edge_links for shared slabs"
         ei = self.t["edge_index"].view(2, self.num_envs, self.E)
-        off = (torch.arange(self.num_envs, device=self.device, dtype=torch.int64) * self.n).view(1, -1, 1)
+        off = (torch.arange(self.num_envs, device=self.device, dtype=torch.int64) * self.n + self.node_id_base).view(1, -1, 1)
         return (ei - off).permute(1, 2, 0).contiguous()
 
 

@@ -52,12 +52,15 @@ typedef struct {
   int32_t weighted;
   int32_t parenting;
   int32_t n_dests;         /* SteinerTree */
-  int32_t spatial;         /* TSP (not built yet -> GE_E_UNSUPPORTED) */
+  int32_t spatial;         /* TSP: node coordinates rand()*10, Euclidean float64 edge weights (tsp.py:79-86) */
   int32_t is_eval_env;
   int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset */
   double n_choices;        /* DensestSubgraph; < 0 -> floor(n / e) as densest_subgraph.py:38-39 */
   int64_t env_index_base;  /* global index of slot 0 (multi-GPU shard of the batch dimension) */
   int64_t seed_stride;     /* episode k of a slot seeded s0 runs reset(seed=(s0 + k*seed_stride) mod 2^32) */
+  int64_t node_id_base;    /* added to every node id written to edge_index: lets several engines of different
+                              geometry share one PyG slab (ragged batch: variable-size CSR packing) */
+  int64_t edge_row_stride; /* elements between the two rows of edge_index; 0 = num_envs * 2 * n_edges */
 } ge_config;
 
 /* Sizes (in elements) of every caller-allocated device buffer for a config. */
@@ -80,6 +83,7 @@ typedef struct {
   uint16_t *colw;       /* [Ne]      (col << 4) | weight code k, weight = k/10.0 (k=10: 1.0) */
   uint8_t *scode;       /* [Ne]      weight codes in ascending-neighbour order per row: the code of u->v sits at
                                      row_ptr[u] + popcount(adj_bits[u] & below(v)) -- a lookup without a row scan */
+  double *sw64;         /* [Ne]      spatial TSP only: float64 edge weights in ascending-neighbour order (else NULL) */
   uint64_t *adj_bits;   /* [Nn, W]   adjacency bit rows                                     */
   uint64_t *node_rec;   /* [Nn, 2]   n <= 64 only: {bit row, weight codes of the 16 smallest neighbours as nibbles}:
                                      everything a step needs about a node in one 16-byte gather (else NULL) */

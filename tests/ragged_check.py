@@ -1,0 +1,65 @@
+"""Shared body of the ragged / mixed batch parity test (BASELINE config 5 shape, reduced): every slot of every size
+class is replayed on the CPU oracle."""
+import numpy as np
+import torch
+
+
+def check_ragged_mixed(ge, oracle, device, library=None, steps=25):
+    kw = dict(device=device, _library=library) if library is not None else dict(device=device)
+    specs = [("ShortestPath-v0", [(3, 32, 96), (2, 45, 135), (2, 64, 192), (1, 130, 390)], {}),
+             ("MaxIndependentSet-v0", [(2, 32, 96), (2, 70, 210)], {}),
+             ("DensestSubgraph-v0", [(2, 33, 96), (2, 90, 270)], dict(parenting=1))]
+    members = [ge.RaggedVectorEnv(eid, sizes, **kw, **extra) for eid, sizes, extra in specs]
+    mixed = ge.MixedVectorEnv(members)
+    graphs, infos = mixed.reset(seed=11)
+    refs = []
+    for (eid, sizes, extra), member, g in zip(specs, members, graphs):
+        slot, rs = 0, []
+        for (b, n, m), cls in zip(sizes, member.classes):
+            for i in range(b):
+                r = oracle.OracleEnv(eid, n_nodes=n, n_edges=m, **extra)
+                r.reset(seed=11 + slot)
+                lo, hi = int(member.ptr[slot]), int(member.ptr[slot + 1])
+                assert hi - lo == n
+                assert np.array_equal(g.x[lo:hi].cpu().numpy(), r.nodes())
+                sel = (g.batch[g.edge_index[0]] == slot)
+                ei = g.edge_index[:, sel].cpu().numpy() - lo
+                assert np.array_equal(ei.T, r.edge_links())
+                assert np.array_equal(g.edge_attr[sel].cpu().numpy(), r.edges())
+                assert np.array_equal(cls.mask[i].cpu().numpy(), r.mask())
+                rs.append((r, n, m, slot))
+                slot += 1
+        assert g.x.shape[0] == int(member.ptr[-1]) and int(g.batch[-1]) == member.num_envs - 1
+        refs.append(rs)
+    episodes = 0
+    tcount = [[0] * len(rs) for rs in refs]
+    for k in range(steps):
+        acts = mixed.sample_random_actions(policy_seed=5)
+        obs, rew, term, trunc, info = mixed.step(acts)
+        for mi, ((eid, sizes, extra), member, rs) in enumerate(zip(specs, members, refs)):
+            a = acts[mi].cpu().numpy(); rw = rew[mi].cpu().numpy(); tm = term[mi].cpu().numpy()
+            flat = info[mi]["mask_flat"].cpu().numpy()
+            off = 0
+            for j, (r, n, m, slot) in enumerate(rs):
+                want_a = oracle.policy_pick(r.mask(), 5, slot, tcount[mi][j])
+                assert int(a[j]) == want_a, (eid, j, k)
+                _, rr, dd, _, _ = r.step(int(a[j]))
+                tcount[mi][j] += 1
+                assert rr == rw[j] and dd == bool(tm[j]), (eid, j, k)
+                if dd:
+                    episodes += 1
+                    ep = tcount[mi][j]  # placeholder to keep the line short
+                    r.reset(seed=(11 + slot + member.num_envs * _episode(member, j)) % 2**32)
+                assert np.array_equal(flat[off:off + r.A], r.mask()), (eid, j, k)
+                off += r.A
+    assert episodes > 0
+    mixed.close()
+
+
+def _episode(member, j):
+    lo = 0
+    for c in member.classes:
+        if j < lo + c.num_envs:
+            return int(c.t["episode"][j - lo])
+        lo += c.num_envs
+    raise IndexError(j)

@@ -18,7 +18,7 @@ FAST = ["sp_n10_m20_eval", "sp_n5_m7", "sp_n33_m70", "sp_n64_m192_eval", "lp_n10
         "st_n10_m20_d1_eval", "st_n10_m20_d3_eval", "st_n10_m20_d9_eval", "st_n5_m10_d4", "tsp_n8_m28_p1",
         "tsp_n10_m20_p1", "tsp_n12_m30_p1_unweighted", "mis_n6_m8", "mis_n5_m7_unweighted", "ds_n10_m20_p1",
         "ds_n10_m20_p0_eval", "ds_n100_m300_p1", "sp_n10_m20_unweighted", "st_n10_m20_d3_unweighted",
-        "lp_n10_m20_p2", "lp_n64_m192_p2", "tsp_n10_m20_p2"]
+        "lp_n10_m20_p2", "lp_n64_m192_p2", "tsp_n10_m20_p2", "tsp_n12_m30_p2_spatial"]
 
 
 @pytest.fixture(scope="module")
@@ -109,3 +109,9 @@ def test_emulated_dense_rows_use_the_scode_fallback(emu):
             assert float(rew[i]) == rr and bool(term[i]) == dd
             assert np.array_equal(info["mask"][i].numpy(), r.mask())
             alive[i] = not dd
+
+
+def test_emulated_ragged_mixed_batch_matches_oracle(emu):
+    import oracle
+    from ragged_check import check_ragged_mixed
+    check_ragged_mixed(ge, oracle, "cpu", library=emu, steps=12)

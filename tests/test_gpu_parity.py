@@ -40,6 +40,8 @@ CASES = [
     ("TSP-v0", dict(n_nodes=16, n_edges=120, parenting=1), 32, 40),
     ("TSP-v0", dict(n_nodes=20, n_edges=60, parenting=1), 32, 50),
     ("TSP-v0", dict(n_nodes=14, n_edges=40, parenting=2), 32, 40),
+    ("TSP-v0", dict(n_nodes=70, n_edges=300, parenting=1, spatial=True), 16, 80),
+    ("TSP-v0", dict(n_nodes=20, n_edges=190, parenting=1, spatial=True), 16, 30),
     ("LongestPath-v0", dict(n_nodes=24, n_edges=50, parenting=2), 48, 40),
     ("LongestPath-v0", dict(n_nodes=100, n_edges=300, parenting=2), 16, 60),
     ("ShortestPath-v0", dict(n_nodes=130, n_edges=400, is_eval_env=True), 16, 60),
@@ -215,3 +217,11 @@ def test_full_size_invariants_and_sampled_oracle_parity(env_id, kw, B, K):
         flat_i = torch.cat([t["x"].view(B, -1)[i], t["edge_attr"].view(B, -1)[i],
                             (t["edge_index"].view(2, B, env.E)[:, i].T - i * env.n).reshape(-1).float()]).cpu().numpy()
         assert np.array_equal(flat_i, refs[i].obs()), i
+
+
+def test_ragged_mixed_batch_matches_oracle():
+    """BASELINE config 5 shape (reduced): {ShortestPath, MaxIndependentSet (= "MinVertexCover"), DensestSubgraph},
+    ragged n, shared PyG slabs per env id."""
+    import oracle
+    from ragged_check import check_ragged_mixed
+    check_ragged_mixed(_ge(), oracle, "cuda", steps=40)
