@@ -68,7 +68,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
   P.node_id_base = cfg->node_id_base;
   P.edge_row_stride = cfg->edge_row_stride > 0 ? cfg->edge_row_stride : (int64_t)cfg->num_envs * 2 * m;
-  P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 128) ? 1 : 0;
+  P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 256) ? 1 : 0;  // nibble matrix of n*n/2 bytes <= 32 KiB
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
@@ -159,10 +159,10 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
     rc = check_launch("feature kernel (n <= 64)");
     if (rc != GE_OK) return rc;
     int g2 = e->gen_grid < 64 ? e->gen_grid : 64;  // normally an empty list
-    GE_LAUNCH(ge_k_features, g2, GE_WAVE, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
+    GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
     return check_launch("feature kernel (fallback list)");
   }
-  GE_LAUNCH(ge_k_features, fgrid, GE_WAVE, e->feat_lds, stream, e->P, mode);
+  GE_LAUNCH(ge_k_features, fgrid, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode);
   return check_launch("feature kernel");
 }
 

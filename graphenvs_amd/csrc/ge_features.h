@@ -12,7 +12,9 @@
 
 struct GeFctx {
   uint64_t *abits; int *rowptr; uint16_t *colw; uint16_t *scw; int *dist;
-  double *sigma, *delta, *coeff, *bc, *prx, *prn, *sinv, *diff, *clos;
+  double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's slice)
+  double *bcw0;                                 // slice of wave 0 (the per-wave partial sums are combined in wave order)
+  double *bc, *prx, *prn, *sinv, *diff, *clos;  // shared
 };
 
 GE_DEV GeFctx ge_carve_f(const GeParams &P) {
@@ -20,36 +22,44 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P) {
   const GeLdsF &L = P.ldsf;
   GeFctx c;
   c.abits = (uint64_t *)(s + L.abits); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
-  c.scw = (uint16_t *)(s + L.scw); c.dist = (int *)(s + L.dist);
+  c.scw = (uint16_t *)(s + L.scw);
+  const int wv = ge_tid() >> 6;
+  c.dist = (int *)(s + L.dist) + wv * P.n;
   double *f = (double *)(s + L.f64a);
-  c.sigma = f; c.delta = f + P.n; c.coeff = f + 2 * P.n; c.bc = f + 3 * P.n; c.prx = f + 4 * P.n;
-  c.prn = f + 5 * P.n; c.sinv = f + 6 * P.n; c.diff = f + 7 * P.n; c.clos = f + 8 * P.n;
+  c.bc = f; c.prx = f + P.n; c.prn = f + 2 * P.n; c.sinv = f + 3 * P.n; c.diff = f + 4 * P.n; c.clos = f + 5 * P.n;
+  double *wsc = f + 6 * P.n;  // [waves][4][n]
+  c.bcw0 = wsc + 3 * P.n;
+  c.sigma = wsc + (wv * 4) * P.n; c.delta = c.sigma + P.n; c.coeff = c.sigma + 2 * P.n; c.bcw = c.sigma + 3 * P.n;
   return c;
 }
 
+// Any n.  The workgroup has 1..8 waves (whatever fits LDS): the graph is staged once, then every wave runs the
+// level-synchronous Brandes pass for its own sources (s = wave, wave + waves, ...) on private scratch; per-wave
+// betweenness partial sums are combined in wave order, then wave 0 does clustering and pagerank.
 GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
-  const int lane = ge_tid();
+  const int tid = ge_tid(), nthreads = ge_bdim();
+  const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
   const int n = P.n, W = P.W, E = P.E, F = P.F, t = P.env_type;
   const ge_buffers &G = P.buf;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   GeFctx c = ge_carve_f(P);
   // stage the slot's graph in LDS
-  for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = G.adj_bits[nbase * W + i];
-  for (int v = lane; v <= n; v += GE_WAVE) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
-  for (int idx = lane; idx < E; idx += GE_WAVE) c.colw[idx] = G.colw[ebase + idx];
+  for (int i = tid; i < n * W; i += nthreads) c.abits[i] = G.adj_bits[nbase * W + i];
+  for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
+  for (int idx = tid; idx < E; idx += nthreads) c.colw[idx] = G.colw[ebase + idx];
   ge_sync();
   // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row
-  for (int v = lane; v < n; v += GE_WAVE)
+  for (int v = tid; v < n; v += nthreads)
     for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
       uint16_t e = c.colw[k];
       c.scw[c.rowptr[v] + ge_rank_below(c.abits + v * W, e >> 4)] = e;
     }
-  for (int v = lane; v < n; v += GE_WAVE) c.bc[v] = 0.0;
+  for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
   ge_sync();
-  // Brandes betweenness + closeness: one level-synchronous BFS per source
-  for (int s = 0; s < n; s++) {
+  // Brandes betweenness + closeness: one level-synchronous BFS per source, sources dealt round-robin to the waves
+  for (int s = wv; s < n; s += nwaves) {
     for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
-    ge_sync();
+    ge_wave_sync();
     int d = 0, reach = 1; int64_t tot = 0;
     for (;;) {  // forward: discover level d+1, sigma by pull from level d
       // a node moves from -1 to d+1, never to d, so lanes still testing dist[u] == d are unaffected
@@ -64,27 +74,32 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
         uint64_t b = ge_ballot(hit);
         any |= b; found += ge_popc64(b);
       }
-      ge_sync();
+      ge_wave_sync();
       if (!any) break;
       d++; reach += found; tot += (int64_t)d * found;
     }
     for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
-      for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev) { c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bc[v] += c.delta[v]; }
-      ge_sync();
+      for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev) { c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bcw[v] += c.delta[v]; }
+      ge_wave_sync();
       for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev - 1) {
         double acc = 0.0, sv = c.sigma[v];
         for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int w = c.colw[k] >> 4; if (c.dist[w] == lev) acc += sv * c.coeff[w]; }
         c.delta[v] = acc;
       }
-      ge_sync();
+      ge_wave_sync();
     }
     if (lane == 0) {  // closeness_centrality, wf_improved
       double cc = 0.0;
       if (tot > 0 && n > 1) { cc = ((double)reach - 1.0) / (double)tot; double sc = ((double)reach - 1.0) / (double)(n - 1); cc *= sc; }
       c.clos[s] = cc;
     }
-    ge_sync();
+    ge_wave_sync();
   }
+  ge_sync();
+  // betweenness: per-wave partial sums (each in source order) added in wave order
+  for (int v = tid; v < n; v += nthreads) { double acc = 0.0; for (int w = 0; w < nwaves; w++) acc += c.bcw0[(w * 4) * n + v]; c.bc[v] = acc; }
+  ge_sync();
+  if (wv == 0) {
   if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
   // clustering (directed formula on the symmetric graph) -> coeff[]
   for (int i = lane; i < n; i += GE_WAVE) {
@@ -108,7 +123,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
     }
     ndang += ge_popc64(ge_ballot(dang));
   }
-  ge_sync();
+  ge_wave_sync();
   const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
   bool conv = false;
   for (int it = 0; it < 100 && !conv; it++) {
@@ -125,10 +140,10 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
       c.prn[i] = xn;
       c.diff[i] = __builtin_fabs(xn - c.prx[i]);
     }
-    ge_sync();
+    ge_wave_sync();
     double err = ge_pw<5>(c.diff, n, lane);
     for (int i = lane; i < n; i += GE_WAVE) c.prx[i] = c.prn[i];
-    ge_sync();
+    ge_wave_sync();
     if (err < (double)n * tol) conv = true;
   }
 
@@ -137,6 +152,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
     float *xr = G.x + (nbase + v) * F + P.nflag;
     xr[0] = (float)(2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]));
     xr[1] = (float)c.bc[v]; xr[2] = (float)c.clos[v]; xr[3] = (float)c.prx[v]; xr[4] = (float)c.coeff[v];
+  }
   }
   ge_sync();
 }
@@ -366,7 +382,12 @@ enum { GE_FEAT_LIST = 3 };  // slots from work_list (fallback of the fast path)
 // mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list
 GE_KERNEL ge_k_features(GeParams P, int mode) {
   int *pre = (int *)(ge_dyn_smem() + P.ldsf.pre);
-  const int count = (mode == GE_RESET_QUEUE) ? ge_queue_prefix(P, pre, ge_tid()) : (mode == GE_FEAT_LIST ? P.buf.work_count[0] : P.B);
+  int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
+  if (mode == GE_RESET_QUEUE) {
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    ge_sync();
+    count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
+  }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
     const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : (mode == GE_FEAT_LIST ? P.buf.work_list[q] : q);
     ge_features_generic_env(P, env);

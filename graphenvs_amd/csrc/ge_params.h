@@ -37,6 +37,7 @@ struct GeLds {
 // LDS carve of the generic structural-feature kernel
 struct GeLdsF {
   int abits, rowptr, colw, scw, dist, f64a, pre, total;
+  int waves;  // waves per workgroup of the generic feature kernel (1..8, as many as LDS allows)
 };
 
 struct GeParams {
@@ -86,8 +87,14 @@ static inline void ge_make_ldsf(GeParams &P) {
   L.rowptr = take((P.n + 1) * 4);
   L.colw = take((P.E > 0 ? P.E : 1) * 2);
   L.scw = take((P.E > 0 ? P.E : 1) * 2);
-  L.dist = take(P.n * 4);
-  L.f64a = take(9 * P.n * 8);
   L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
+  const int shared = o + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
+  int waves = (160 * 1024 / 2 - shared) / (per_wave > 0 ? per_wave : 1);  // aim at two workgroups per CU
+  if (waves > 8) waves = 8;
+  if (waves < 1) waves = 1;
+  if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here
+  L.waves = waves;
+  L.dist = take(waves * P.n * 4);
+  L.f64a = take((6 + 4 * waves) * P.n * 8);
   L.total = o;
 }

@@ -1,0 +1,24 @@
+"""env-steps/s of the other BASELINE configs (parity-test cases, not the bench line): device policy, autoreset on.
+Usage: python tools/bench_configs.py [c3] [c4] [c2]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import graphenvs_amd as ge
+
+CONFIGS = {
+    "c2": ("ShortestPath-v0", dict(n_nodes=64, n_edges=192), 65536, 200),
+    "c3": ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), 16384, 130),
+    "c4": ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 16384, 100),
+    "mis": ("MaxIndependentSet-v0", dict(n_nodes=64, n_edges=192), 65536, 130),
+    "ds": ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 65536, 100),
+}
+for name in (sys.argv[1:] or ["c3", "c4"]):
+    env_id, kw, B, K = CONFIGS[name]
+    env = ge.make_vec(env_id, B, **kw)
+    t0 = time.perf_counter(); env.reset(seed=0); torch.cuda.synchronize(); t_reset = time.perf_counter() - t0
+    env.random_rollout(10, policy_seed=1); torch.cuda.synchronize()
+    ep0 = int(env.t["episode"].sum())
+    t0 = time.perf_counter(); env.random_rollout(K, policy_seed=1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps(dict(config=name, env=env_id, kwargs=kw, envs=B, steps=K, env_steps_per_s=B * K / dt, ms_per_vector_step=dt * 1e3 / K,
+                          episodes=int(env.t["episode"].sum()) - ep0, full_reset_ms=t_reset * 1e3)), flush=True)
+    env.close(); del env; torch.cuda.empty_cache()
