@@ -45,7 +45,7 @@ class GeLayout(C.Structure):
 
 BUFFER_FIELDS = [
     "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "head", "cur_rec", "terminals",
-    "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic",
+    "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic", "mt_state",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
     "final_len", "reset_list", "reset_count", "work_list", "work_count",
 ]

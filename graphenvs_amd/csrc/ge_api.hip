@@ -20,6 +20,10 @@ struct ge_engine {
   int feat_lds, feat_grid, feat_fast, gen_grid;  // structural-feature kernel launch geometry
   hipEvent_t ev[4];
   bool have_events;
+  hipStream_t side;        // side stream of the MT19937 pre-seeding kernel
+  hipEvent_t ev_graph;     // main stream: the graph kernel has consumed the states of this step's slots
+  hipEvent_t ev_seeded;    // side stream: the next states are written
+  bool seed_pending;
 };
 
 static thread_local char g_err[256] = "";
@@ -97,7 +101,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   if (rc != GE_OK) return rc;
   const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->scode, bufs->adj_bits, bufs->head,
                         bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->cost, bufs->counters, bufs->seed,
-                        bufs->episode, bufs->tstep, bufs->status, bufs->heuristic, bufs->mask, bufs->mask_bits, bufs->reward,
+                        bufs->episode, bufs->tstep, bufs->status, bufs->heuristic, bufs->mt_state, bufs->mask, bufs->mask_bits, bufs->reward,
                         bufs->terminated, bufs->invalid, bufs->solved, bufs->final_cost, bufs->final_heur, bufs->final_len,
                         bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
@@ -107,6 +111,9 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   P.buf = *bufs;
   ge_engine *e = new (std::nothrow) ge_engine();
   if (!e) return fail(GE_E_BADARG, "out of host memory");
+  e->seed_pending = false;
+  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_graph, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_seeded, hipEventDisableTiming) != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot create the side stream"); }
   e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false;
   int per_cu = kMaxLds / (P.lds.total > 0 ? P.lds.total : 1);
   if (per_cu > 16) per_cu = 16;
@@ -137,6 +144,8 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
 
 extern "C" int ge_destroy(ge_engine *e) {
   if (!e) return GE_OK;
+  (void)hipStreamSynchronize(e->side);
+  (void)hipStreamDestroy(e->side); (void)hipEventDestroy(e->ev_graph); (void)hipEventDestroy(e->ev_seeded);
   if (e->have_events) for (int k = 0; k < 4; k++) (void)hipEventDestroy(e->ev[k]);
   delete e;
   return GE_OK;
@@ -148,11 +157,38 @@ static int check_launch(const char *what) {
   return GE_OK;
 }
 
+static int launch_seed(ge_engine *e, const uint32_t *seeds, int smode, hipStream_t st) {
+  int count = e->P.B;
+  int grid = (count + 255) / 256;
+  size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
+  GE_LAUNCH(ge_k_seed, grid, 256, lds, st, e->P, seeds, smode);
+  return check_launch("seed kernel");
+}
+
+// main stream must not touch seed[] / reset_list / mt_state while the side stream's seeding kernel reads or writes them
+static void wait_seeded(ge_engine *e, void *stream) {
+  if (e->seed_pending) { (void)hipStreamWaitEvent((hipStream_t)stream, e->ev_seeded, 0); e->seed_pending = false; }
+}
+
 static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, void *stream) {
+  int rc = GE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == GE_RESET_ALL) {  // states of episode 0 on the main stream, right in front of their consumer
+    wait_seeded(e, stream);
+    rc = launch_seed(e, seeds, GE_SEED_GIVEN, st);
+    if (rc != GE_OK) return rc;
+  }
   int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
   GE_LAUNCH(ge_k_reset, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj);
-  int rc = check_launch("reset kernel");
+  rc = check_launch("reset kernel");
   if (rc != GE_OK || mode == GE_RESET_INJECT) return rc;
+  // the slots just regenerated get the states of their next episode, on the side stream, beside the feature kernel
+  (void)hipEventRecord(e->ev_graph, st);
+  (void)hipStreamWaitEvent(e->side, e->ev_graph, 0);
+  rc = launch_seed(e, seeds, mode == GE_RESET_ALL ? GE_SEED_GIVEN_NEXT : GE_SEED_QUEUE_NEXT, e->side);
+  if (rc != GE_OK) return rc;
+  (void)hipEventRecord(e->ev_seeded, e->side);
+  e->seed_pending = true;
   int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);
   if (e->feat_fast) {
     GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode);
@@ -193,6 +229,7 @@ static bool path64(const ge_engine *e) {
 
 extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {
   if (!e || !actions) return fail(GE_E_BADARG, "null argument");
+  wait_seeded(e, stream);
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0);
   else GE_LAUNCH(ge_k_step, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions);
@@ -201,6 +238,7 @@ extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) 
 
 // sample + step in one launch where the fused kernel exists, else two launches; `scratch` receives the actions
 static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch, void *stream) {
+  wait_seeded(e, stream);
   if (path64(e)) {
     int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
     GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, scratch, policy_seed);
@@ -293,6 +331,20 @@ extern "C" int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k
   *burst_ms = ms;
   return GE_OK;
 }
+
+#if !defined(GE_EMU)
+// diagnostic (tools/occupancy.py): resident workgroups per CU the runtime reports for the reset-path kernels
+extern "C" int ge_debug_occupancy(ge_engine *e, int *out4) {
+  if (!e || !out4) return GE_E_BADARG;
+  int a = -1, b = -1, c = -1, d = -1;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ge_k_reset, GE_RESET_THREADS, e->lds_bytes);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ge_k_features64, GE_F64_THREADS, e->feat_lds);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ge_k_features, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, ge_k_step_path64<true>, GE_STEP_BLOCK, step_lds(e));
+  out4[0] = a; out4[1] = b; out4[2] = c; out4[3] = d;
+  return GE_OK;
+}
+#endif
 
 #if defined(GE_STAMPS) && !defined(GE_EMU)
 // diagnostic build only: copy out the phase timestamps of slot 0 (synchronises)

@@ -246,19 +246,15 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
       if ((su | su2) > 1023u) ovf = true;            // 64 parents x 1023 still fit the 16-bit counters
       uint64_t cand = c.abits[u] & ~visited, cand2 = two ? (c.abits[u2] & ~visited) : 0ull;
       nxt |= cand | cand2;
-      while (cand | cand2) {
-        const uint64_t t0 = cand, t1 = t0 & (t0 - 1), t2 = t1 & (t1 - 1), t3 = t2 & (t2 - 1);
-        cand = t3 & (t3 - 1);
-        const uint64_t r0 = cand2, r1 = r0 & (r0 - 1), r2 = r1 & (r1 - 1), r3 = r2 & (r2 - 1);
-        cand2 = r3 & (r3 - 1);
-        const uint64_t mine = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
-        const uint64_t mine2 = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;
+      // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
+      uint32_t mine = (uint32_t)(cand >> (16 * q)) & 0xffffu, mine2 = (uint32_t)(cand2 >> (16 * q)) & 0xffffu;
+      while (mine | mine2) {
         if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
-          const int idx = ge_ctz64(mine) * GE_F64_SS + s;
+          const int idx = (16 * q + (int)__builtin_ctz(mine)) * GE_F64_SS + s; mine &= mine - 1;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su << (16 * (idx & 1)));
         }
         if (mine2) {
-          const int idx = ge_ctz64(mine2) * GE_F64_SS + s;
+          const int idx = (16 * q + (int)__builtin_ctz(mine2)) * GE_F64_SS + s; mine2 &= mine2 - 1;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su2 << (16 * (idx & 1)));
         }
       }
@@ -333,16 +329,12 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
       if (q == 0) { c.del[w * GE_F64_SD + s] = dw; if (two) c.del[w2 * GE_F64_SD + s] = dw2; }
       const double coeff = (1.0 + dw) / sg, coeff2 = (1.0 + dw2) / sg2;
       uint64_t pb = c.abits[w] & prev, pb2 = two ? (c.abits[w2] & prev) : 0ull;
-      while (pb | pb2) {
-        const uint64_t t0 = pb, t1 = t0 & (t0 - 1), t2 = t1 & (t1 - 1), t3 = t2 & (t2 - 1);
-        pb = t3 & (t3 - 1);
-        const uint64_t r0 = pb2, r1 = r0 & (r0 - 1), r2 = r1 & (r1 - 1), r3 = r2 & (r2 - 1);
-        pb2 = r3 & (r3 - 1);
-        const uint64_t mine = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
-        const uint64_t mine2 = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;
-        if (mine) ge_lds_add_f64(&c.del[ge_ctz64(mine) * GE_F64_SD + s], coeff);  // ds_add_f64, fire and forget
-        ge_quad_sync();  // same-target adds of w and w2 keep their order (w first) in every run
-        if (mine2) ge_lds_add_f64(&c.del[ge_ctz64(mine2) * GE_F64_SD + s], coeff2);
+      // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same
+      // lane, w before w2, iteration after iteration: the float64 sum order is fixed
+      uint32_t mine = (uint32_t)(pb >> (16 * q)) & 0xffffu, mine2 = (uint32_t)(pb2 >> (16 * q)) & 0xffffu;
+      while (mine | mine2) {
+        if (mine) { ge_lds_add_f64(&c.del[(16 * q + (int)__builtin_ctz(mine)) * GE_F64_SD + s], coeff); mine &= mine - 1; }  // ds_add_f64
+        if (mine2) { ge_lds_add_f64(&c.del[(16 * q + (int)__builtin_ctz(mine2)) * GE_F64_SD + s], coeff2); mine2 &= mine2 - 1; }
       }
     }
   }

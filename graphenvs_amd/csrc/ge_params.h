@@ -75,7 +75,8 @@ static inline void ge_make_lds(GeParams &P) {
   { int need = 2 * P.n * 8, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
   L.bits = take(6 * P.W * 8);
   L.misc = take(16 * 4);
-  L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
+  // the queue prefix is only needed while a workgroup looks up its slot: it overlays the scratch that follows
+  { int pb = ((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4; L.pre = L.mt; if (pb > GE_MT_N * 8) { L.pre = take(pb); } }
   L.total = o;
 }
 

@@ -275,10 +275,11 @@ GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, in
 
 // The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
 // depend on the topology runs beside the python-stream graph sampling of the first wave.
-GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, uint32_t seed, int lane) {
+GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane) {
   const int t = P.env_type, n = P.n;
   if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
-  ge_mt_seed_numpy(c.mt2, seed, lane);
+  for (int i = lane; i < GE_MT_N; i += GE_WAVE) c.mt2[i] = P.buf.mt_state[((int64_t)env * 2 + 1) * GE_MT_N + i];  // pre-seeded
+  ge_wave_sync();
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
   const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
@@ -319,7 +320,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   int src = 0, dest = -1;
   if (wv == 1) {
-    if (mode != GE_RESET_INJECT) { ge_numpy_wave(P, c, seed, lane); ge_sync(); }
+    if (mode != GE_RESET_INJECT) { ge_numpy_wave(P, c, env, lane); ge_sync(); }
     ge_sync();
     return;
   }
@@ -327,7 +328,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   GE_STAMP(0);
   if (mode != GE_RESET_INJECT) {
     // ---------------------------------------------------------------- topology (python stream)
-    ge_mt_seed_python(c.mt, seed, lane);
+    for (int i = lane; i < GE_MT_N; i += GE_WAVE) c.mt[i] = P.buf.mt_state[(int64_t)env * 2 * GE_MT_N + i];  // pre-seeded (ge_k_seed)
+    ge_wave_sync();
     GE_STAMP(1);
     int pypos = GE_MT_N;
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
@@ -741,17 +743,70 @@ GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
   return P.buf.reset_list[lo * GE_STEP_BLOCK + (q - pre[lo])];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// MT19937 pre-seeding, one LANE per slot.  Seeding is a chain of 1 246 + 623 dependent steps; inside the reset
+// workgroup it kept one lane busy and 63 idle.  Here 64 slots seed side by side and the kernel runs on the engine's
+// side stream while the feature kernel of the same vector step occupies the main stream, so neither its latency nor
+// its instructions are on the step's critical path.  State layout [slot][stream][624]: the reset workgroup loads
+// its 2 x 2.5 KB with coalesced reads.
+enum { GE_SEED_GIVEN = 0, GE_SEED_GIVEN_NEXT = 1, GE_SEED_QUEUE_NEXT = 2 };
+
+GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int mode) {
+  int *pre = (int *)ge_dyn_smem();
+  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  int count = P.B;
+  if (mode == GE_SEED_QUEUE_NEXT) {
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    ge_sync();
+    count = pre[nblk];
+  }
+  const int g = ge_bid() * ge_bdim() + ge_tid();
+  if (g >= count) return;
+  const int env = (mode == GE_SEED_QUEUE_NEXT) ? ge_queue_slot(P, pre, g) : g;
+  uint32_t seed = (mode == GE_SEED_QUEUE_NEXT) ? P.buf.seed[env] : seeds[env];
+  if (mode != GE_SEED_GIVEN) seed += (uint32_t)P.seed_stride;
+  uint32_t *mt = P.buf.mt_state + (int64_t)env * 2 * GE_MT_N;
+  {  // python: init_by_array([seed])
+    uint32_t b = 19650218u, prev = b;
+    for (int i = 1; i < GE_MT_N; i++) {
+      b = 1812433253u * (b ^ (b >> 30)) + (uint32_t)i;
+      prev = (b ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;
+      mt[i] = prev;
+    }
+    prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;
+    uint32_t m1 = prev;
+    for (int i = 2; i < GE_MT_N; i++) {
+      prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+      mt[i] = prev;
+    }
+    mt[1] = (m1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+    mt[0] = 0x80000000u;
+  }
+  {  // numpy: init_genrand(seed)
+    uint32_t *mn = mt + GE_MT_N, prev = seed;
+    mn[0] = prev;
+    for (int i = 1; i < GE_MT_N; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; mn[i] = prev; }
+  }
+}
+
 GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj) {
-  int *pre = (int *)(ge_dyn_smem() + P.lds.pre);
+  int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
+  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
-    count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
+    count = pre[nblk];
   }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    int env = q;
+    if (mode == GE_RESET_QUEUE) {
+      if (q != ge_bid()) { if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid()); ge_sync(); }
+      env = ge_queue_slot(P, pre, q);
+      ge_sync();  // every thread has its slot before the scratch is reused
+    }
     uint32_t seed = (mode == GE_RESET_ALL) ? seeds[env] : ((mode == GE_RESET_QUEUE) ? P.buf.seed[env] : 0u);
     ge_reset_env(P, env, seed, mode, inj);
   }

@@ -140,6 +140,7 @@ class VectorGraphEnv:
         t["tstep"] = z((B,), torch.int64)
         t["status"] = z((B,), torch.uint8)
         t["heuristic"] = z((B,), torch.float64)
+        t["mt_state"] = z((B, 2, 624), torch.int32)
         t["mask"] = z((B, A), torch.uint8)
         t["mask_bits"] = z((B, AW), torch.int64)
         t["reward"] = z((B,), torch.float64)

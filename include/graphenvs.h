@@ -8,8 +8,9 @@
  * Conventions
  *  - plain C types only; every buffer pointer is a DEVICE pointer owned by the caller
  *    (the Python host allocates them with torch); the library never allocates device memory;
- *  - every launch goes to the hipStream_t passed as `stream` (void*, NULL = default stream);
- *    no call synchronises the stream or the device;
+ *  - every launch goes to the hipStream_t passed as `stream` (void*, NULL = default stream), except the
+ *    MT19937 pre-seeding kernel, which runs on a side stream the engine owns and is ordered against
+ *    `stream` with events; no call synchronises the stream or the device;
  *  - int return code: GE_OK or a negative GE_E_* value; no exceptions cross the ABI;
  *  - gfx950 only.
  */
@@ -101,6 +102,8 @@ typedef struct {
   int64_t *tstep;       /* [B]  transitions executed by the slot since creation              */
   uint8_t *status;      /* [B]  0 = running, 1 = finished (autoreset off), 2 = needs reset   */
   double *heuristic;    /* [B]  heuristic_solution of the current episode (is_eval_env)      */
+  uint32_t *mt_state;   /* [B, 2, 624] MT19937 states (python stream, numpy stream) already seeded for the slot's NEXT
+                                 reset: seeded one lane per slot by a helper kernel on the engine's side stream */
   /* --- outputs of the last step / reset */
   uint8_t *mask;        /* [B, A] info['mask'] as bool bytes                                 */
   uint64_t *mask_bits;  /* [B, ceil(A/64)] same, packed                                      */

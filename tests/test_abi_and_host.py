@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_field_counts():
     header = open(os.path.join(ROOT, "include", "graphenvs.h")).read()
     body = header[header.index("typedef struct {\n  /* --- observation"):header.index("} ge_buffers;")]
-    fields = re.findall(r"\*\s*([a-z_]+);", body)
+    fields = re.findall(r"\*\s*([a-z_0-9]+);", body)
     assert fields == _lib.BUFFER_FIELDS
 
 
