@@ -34,6 +34,7 @@ def test_hip_engine_replays_reference_golden(name):
 CASES = [
     ("ShortestPath-v0", dict(n_nodes=64, n_edges=192, is_eval_env=True), 256, 60),
     ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, weighted=False), 64, 30),
+    ("ShortestPath-v0", dict(n_nodes=28, n_edges=32, is_eval_env=True), 48, 30),  # deep sparse graphs: feature fallback list, many rejections
     ("LongestPath-v0", dict(n_nodes=20, n_edges=50, parenting=1, is_eval_env=True), 64, 40),
     ("SteinerTree-v0", dict(n_nodes=40, n_edges=100, n_dests=5), 64, 80),
     ("SteinerTree-v0", dict(n_nodes=30, n_edges=80, n_dests=29, is_eval_env=True), 32, 60),
