@@ -317,17 +317,15 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
         continue;
       }
       ge_quad_sync();
-      // two nodes of the level per iteration (independent division chains overlap).  del[w] holds S = sum of coeff
-      // over w's DAG successors (deeper level, finished); delta[w] = sigma[w] * S is stored for the betweenness sum
-      // and coeff[w] = (1 + delta[w]) / sigma[w] is pushed to w's predecessors.
+      // two nodes of the level per iteration (independent division chains overlap).  del[w] holds S(w) = sum of
+      // coeff over w's DAG successors (deeper level, finished); delta(w) = sigma(w) * S(w) and coeff(w) =
+      // (1 + delta(w)) / sigma(w) is pushed to w's predecessors.  S stays in del[]: the betweenness reduction
+      // multiplies by sigma again, so nothing is rewritten here.
       const int w = ge_ctz64(cur); cur &= cur - 1;
       const bool two = cur != 0;
       const int w2 = two ? ge_ctz64(cur) : w; cur &= cur - 1;
       const double sg = (double)c.sig[w * GE_F64_SS + s], sg2 = (double)c.sig[w2 * GE_F64_SS + s];
-      const double dw = sg * c.del[w * GE_F64_SD + s], dw2 = sg2 * c.del[w2 * GE_F64_SD + s];
-      ge_quad_sync();  // every lane of the quad has read S before lane 0 replaces it by delta
-      if (q == 0) { c.del[w * GE_F64_SD + s] = dw; if (two) c.del[w2 * GE_F64_SD + s] = dw2; }
-      const double coeff = (1.0 + dw) / sg, coeff2 = (1.0 + dw2) / sg2;
+      const double coeff = (1.0 + sg * c.del[w * GE_F64_SD + s]) / sg, coeff2 = (1.0 + sg2 * c.del[w2 * GE_F64_SD + s]) / sg2;
       uint64_t pb = c.abits[w] & prev, pb2 = two ? (c.abits[w2] & prev) : 0ull;
       // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same
       // lane, w before w2, iteration after iteration: the float64 sum order is fixed
@@ -355,7 +353,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
   double bc = 0.0;
   if (live) {
-    for (int src = 0; src < n; src++) if (src != lane) bc += c.del[lane * GE_F64_SD + src];
+    for (int src = 0; src < n; src++) if (src != lane) bc += (double)c.sig[lane * GE_F64_SS + src] * c.del[lane * GE_F64_SD + src];  // delta = sigma * S
     if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
   }
   const double clos = live ? c.clos[lane] : 0.0;

@@ -29,6 +29,9 @@ GE_DEV void ge_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup
 // Ordering point between the four lanes of a quad that execute identical control flow: LDS operations of one wave
 // are performed in issue order, so only the compiler has to be kept from moving accesses across this point.
 GE_DEV void ge_quad_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// value of the lane (lane ^ 1) / (lane ^ 2) inside the quad: one DPP move (quad_perm), no LDS
+GE_DEV uint32_t ge_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }
+GE_DEV uint32_t ge_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }
 // fire-and-forget LDS adds (ds_add_u32 / ds_add_f64, no return value, nothing to wait for)
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 GE_DEV void ge_lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }

@@ -183,6 +183,18 @@ GE_DEV int ge_shfl_i32(int v, int src) { return (int)(int64_t)ge_shfl_u64((uint6
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)ge_shfl_u64(v, src); }
 GE_DEV double ge_shfl_f64(double v, int src) { uint64_t u; memcpy(&u, &v, 8); u = ge_shfl_u64(u, src); memcpy(&v, &u, 8); return v; }
 
+GE_DEV uint32_t ge_quad_xchg(uint32_t v, int xr) {
+  ge_emu::Block &b = ge_emu::blk();
+  static uint32_t qslot[ge_emu::kMaxThreads];
+  qslot[b.cur] = v;
+  int me = b.cur;
+  ge_quad_sync();
+  uint32_t r = qslot[me ^ xr];
+  ge_quad_sync();
+  return r;
+}
+GE_DEV uint32_t ge_quad_xor1(uint32_t v) { return ge_quad_xchg(v, 1); }
+GE_DEV uint32_t ge_quad_xor2(uint32_t v) { return ge_quad_xchg(v, 2); }
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 GE_DEV void ge_lds_add_f64(double *p, double v) { *p += v; }
 GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return v; }
