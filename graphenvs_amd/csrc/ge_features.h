@@ -193,8 +193,12 @@ GE_DEV int *ge_f64_pre(int E, int tsp, int nblk) { return (int *)(ge_dyn_smem() 
 // per node): it computes clustering and pagerank WHILE the walkers run their forward pass, then reduces
 // betweenness / closeness and writes the five columns.  Slots that are too deep or whose path counts exceed the
 // 16-bit counters are appended to work_list for the generic kernel.
-#define GE_F64_THREADS 320
-#define GE_F64_WALKERS 256
+#ifndef GE_F64_QL
+#define GE_F64_QL 4  // lanes per BFS source (4 = quad: 16 sources per wave, 4 walker waves; 2 = pair: 32 per wave, 2 waves)
+#endif
+#define GE_F64_WALKERS (64 * GE_F64_QL)
+#define GE_F64_THREADS (GE_F64_WALKERS + 64)
+#define GE_F64_SLICE (64 / GE_F64_QL)  // nodes per lane slice
 GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   const int tid = ge_tid();
   const bool node_wave = tid >= GE_F64_WALKERS;
@@ -220,8 +224,9 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   // Four lanes (a quad) per source, 16 sources per wave: the quad keeps identical copies of the walk state and
   // splits the pushes of a node -- lane q takes the q-th, (q+4)-th, ... target -- so a node's DAG edges are
   // served in parallel while the per-source order of the float64 delta sums stays fixed.
-  const int s = (tid >> 6) * 16 + ((tid & 63) >> 2);
-  const int q = tid & 3;
+  const int s = (tid >> 6) * (64 / GE_F64_QL) + ((tid & 63) / GE_F64_QL);
+  const int q = tid & (GE_F64_QL - 1);
+  const uint32_t slice_mask = (GE_F64_SLICE == 32) ? 0xffffffffu : ((1u << (GE_F64_SLICE & 31)) - 1u);
   const bool walker = !node_wave && s < n;
   bool ovf = false;
   int D = 0, reach = 1; int64_t tot = 0;
@@ -247,14 +252,14 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
       uint64_t cand = c.abits[u] & ~visited, cand2 = two ? (c.abits[u2] & ~visited) : 0ull;
       nxt |= cand | cand2;
       // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
-      uint32_t mine = (uint32_t)(cand >> (16 * q)) & 0xffffu, mine2 = (uint32_t)(cand2 >> (16 * q)) & 0xffffu;
+      uint32_t mine = (uint32_t)(cand >> (GE_F64_SLICE * q)) & slice_mask, mine2 = (uint32_t)(cand2 >> (GE_F64_SLICE * q)) & slice_mask;
       while (mine | mine2) {
         if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
-          const int idx = (16 * q + (int)__builtin_ctz(mine)) * GE_F64_SS + s; mine &= mine - 1;
+          const int idx = (GE_F64_SLICE * q + (int)__builtin_ctz(mine)) * GE_F64_SS + s; mine &= mine - 1;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su << (16 * (idx & 1)));
         }
         if (mine2) {
-          const int idx = (16 * q + (int)__builtin_ctz(mine2)) * GE_F64_SS + s; mine2 &= mine2 - 1;
+          const int idx = (GE_F64_SLICE * q + (int)__builtin_ctz(mine2)) * GE_F64_SS + s; mine2 &= mine2 - 1;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su2 << (16 * (idx & 1)));
         }
       }
@@ -329,10 +334,10 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
       uint64_t pb = c.abits[w] & prev, pb2 = two ? (c.abits[w2] & prev) : 0ull;
       // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same
       // lane, w before w2, iteration after iteration: the float64 sum order is fixed
-      uint32_t mine = (uint32_t)(pb >> (16 * q)) & 0xffffu, mine2 = (uint32_t)(pb2 >> (16 * q)) & 0xffffu;
+      uint32_t mine = (uint32_t)(pb >> (GE_F64_SLICE * q)) & slice_mask, mine2 = (uint32_t)(pb2 >> (GE_F64_SLICE * q)) & slice_mask;
       while (mine | mine2) {
-        if (mine) { ge_lds_add_f64(&c.del[(16 * q + (int)__builtin_ctz(mine)) * GE_F64_SD + s], coeff); mine &= mine - 1; }  // ds_add_f64
-        if (mine2) { ge_lds_add_f64(&c.del[(16 * q + (int)__builtin_ctz(mine2)) * GE_F64_SD + s], coeff2); mine2 &= mine2 - 1; }
+        if (mine) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + (int)__builtin_ctz(mine)) * GE_F64_SD + s], coeff); mine &= mine - 1; }  // ds_add_f64
+        if (mine2) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + (int)__builtin_ctz(mine2)) * GE_F64_SD + s], coeff2); mine2 &= mine2 - 1; }
       }
     }
   }

@@ -51,6 +51,10 @@ namespace ge_emu {
 
 constexpr int kMaxThreads = 1024;
 constexpr int kWave = 64;
+#ifndef GE_F64_QL
+#define GE_F64_QL 4
+#endif
+constexpr int kQuad = GE_F64_QL;  // lanes that run identical control flow in the feature walk
 constexpr size_t kStack = 256 * 1024;
 
 struct Fiber {
@@ -123,10 +127,10 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
       for (int t = w * kWave; t < nthreads && t < (w + 1) * kWave; t++) if (!b.fib[t].done) { wl++; if (b.fib[t].waiting == 2) ww++; }
       if (wl && ww == wl) { for (int t = w * kWave; t < nthreads && t < (w + 1) * kWave; t++) if (b.fib[t].waiting == 2) b.fib[t].waiting = 0; b.wave_gen[w]++; released = true; }
     }
-    for (int q0 = 0; q0 < nthreads; q0 += 4) {  // quads (4 consecutive lanes running identical control flow)
+    for (int q0 = 0; q0 < nthreads; q0 += kQuad) {  // groups of consecutive lanes running identical control flow
       int ql = 0, qw = 0;
-      for (int t = q0; t < nthreads && t < q0 + 4; t++) if (!b.fib[t].done) { ql++; if (b.fib[t].waiting == 3) qw++; }
-      if (ql && qw == ql) { for (int t = q0; t < nthreads && t < q0 + 4; t++) if (b.fib[t].waiting == 3) b.fib[t].waiting = 0; released = true; }
+      for (int t = q0; t < nthreads && t < q0 + kQuad; t++) if (!b.fib[t].done) { ql++; if (b.fib[t].waiting == 3) qw++; }
+      if (ql && qw == ql) { for (int t = q0; t < nthreads && t < q0 + kQuad; t++) if (b.fib[t].waiting == 3) b.fib[t].waiting = 0; released = true; }
     }
     if (!progressed && !released) die("deadlock: a barrier or wave collective was not reached by every live lane (divergent rendezvous)");
   }

@@ -226,3 +226,49 @@ def test_ragged_mixed_batch_matches_oracle():
     import oracle
     from ragged_check import check_ragged_mixed
     check_ragged_mixed(_ge(), oracle, "cuda", steps=40)
+
+
+def test_soak_many_episodes_sampled_slots_match_oracle():
+    """600 vector steps at B = 8192 (about 200 000 regenerated episodes): 64 sampled slots are replayed on the oracle
+    step by step, and their full observation (all five structural columns included) is compared after every reset."""
+    import oracle
+    ge = _ge()
+    B, K, n, m = 8192, 600, 64, 192
+    env = ge.make_vec("ShortestPath-v0", B, n_nodes=n, n_edges=m, is_eval_env=True)
+    env.reset(seed=77)
+    sample = sorted(set(np.random.default_rng(1).integers(0, B, 64).tolist()))
+    idx = torch.tensor(sample, device="cuda")
+    refs = {i: oracle.OracleEnv("ShortestPath-v0", n_nodes=n, n_edges=m, is_eval_env=True) for i in sample}
+    seeds = {i: 77 + i for i in sample}
+    for i in sample:
+        refs[i].reset(seed=seeds[i])
+    resets = 0
+    E, F = env.E, env.F
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=9)
+        a_s = a[idx].cpu().numpy()
+        obs, rew, term, trunc, info = env.step(a)
+        rs, ts, ms = rew[idx].cpu().numpy(), term[idx].cpu().numpy(), info["mask"][idx].cpu().numpy()
+        fh = info["heuristic_solution"][idx].cpu().numpy()
+        changed = []
+        for j, i in enumerate(sample):
+            _, rr, dd, _, inf = refs[i].step(int(a_s[j]))
+            assert rr == rs[j] and dd == bool(ts[j]), (k, i)
+            if dd:
+                assert fh[j] == inf["heuristic_solution"], (k, i)
+                seeds[i] = (seeds[i] + B) % 2**32
+                refs[i].reset(seed=seeds[i])
+                changed.append((j, i))
+                resets += 1
+            assert np.array_equal(ms[j], refs[i].mask()), (k, i)
+        if changed:
+            x = env.t["x"].view(B, n * F)[idx].cpu().numpy()
+            ea = env.t["edge_attr"].view(B, E)[idx].cpu().numpy()
+            ei = env.t["edge_index"].view(2, B, E)[:, idx].cpu().numpy()
+            for j, i in changed:
+                want = refs[i].obs()
+                assert np.array_equal(x[j], want[: n * F]), (k, i, "x incl. structural features")
+                assert np.array_equal(ea[j], want[n * F: n * F + E]), (k, i)
+                links = (ei[:, j].T - i * n).reshape(-1).astype(np.float32)
+                assert np.array_equal(links, want[n * F + E:]), (k, i)
+    assert resets > 1000 and int(env.t["work_count"][0]) >= 0
