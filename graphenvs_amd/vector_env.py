@@ -314,12 +314,21 @@ class VectorGraphEnv:
         self._was_reset = True
         return self._obs(), self._info(False)
 
+    def _quiesce(self):
+        # the MT19937 pre-seeding kernel runs on the engine's side stream: drain the device before touching the slabs
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def state_dict(self):
+        """Snapshot of every engine slab (the whole state of the batch, generator states included)."""
+        self._quiesce()
         return {k: v.clone() for k, v in self.t.items() if v is not None}
 
     def load_state_dict(self, sd):
+        self._quiesce()
         for k, v in sd.items():
             self.t[k].copy_(v)
+        self._quiesce()
 
     def edge_links(self):
         """[B, E, 2] local node ids (GraphInstance.edge_links of every slot)."""

@@ -115,3 +115,14 @@ def test_emulated_ragged_mixed_batch_matches_oracle(emu):
     import oracle
     from ragged_check import check_ragged_mixed
     check_ragged_mixed(ge, oracle, "cpu", library=emu, steps=12)
+
+
+@pytest.mark.parametrize("env_id,kw", [("ShortestPath-v0", dict(n_nodes=12, n_edges=30)),
+                                       ("SteinerTree-v0", dict(n_nodes=12, n_edges=30, n_dests=4)),
+                                       ("TSP-v0", dict(n_nodes=9, n_edges=20, parenting=1)),
+                                       ("MaxIndependentSet-v0", dict(n_nodes=9, n_edges=14)),
+                                       ("DensestSubgraph-v0", dict(n_nodes=12, n_edges=24, parenting=1))])
+def test_emulated_inject_state_then_step(emu, env_id, kw):
+    import oracle
+    from inject_check import check_inject
+    check_inject(ge, oracle, "cpu", env_id, kw, library=emu)

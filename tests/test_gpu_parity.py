@@ -272,3 +272,51 @@ def test_soak_many_episodes_sampled_slots_match_oracle():
                 links = (ei[:, j].T - i * n).reshape(-1).astype(np.float32)
                 assert np.array_equal(links, want[n * F + E:]), (k, i)
     assert resets > 1000 and int(env.t["work_count"][0]) >= 0
+
+
+@pytest.mark.parametrize("env_id,kw", [("ShortestPath-v0", dict(n_nodes=40, n_edges=100)),
+                                       ("LongestPath-v0", dict(n_nodes=20, n_edges=50, parenting=1)),
+                                       ("SteinerTree-v0", dict(n_nodes=70, n_edges=200, n_dests=6)),
+                                       ("TSP-v0", dict(n_nodes=12, n_edges=40, parenting=1)),
+                                       ("MaxIndependentSet-v0", dict(n_nodes=20, n_edges=40)),
+                                       ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=80, parenting=1))])
+def test_inject_state_then_step_matches_oracle(env_id, kw):
+    """ge_inject_state: the oracle's post-reset states are loaded instead of sampled (SURVEY 7 parity path)."""
+    import oracle
+    from inject_check import check_inject
+    check_inject(_ge(), oracle, "cuda", env_id, kw, B=16, steps=80)
+
+
+def test_tsp_degenerate_start_action_and_dead_end():
+    """tsp.py:203-211: choosing the start node while standing on it ends the episode with reward -n, cost -1."""
+    import oracle
+    ge = _ge()
+    kw = dict(n_nodes=10, n_edges=20, parenting=1)
+    env = ge.make_vec("TSP-v0", 4, autoreset=False, **kw)
+    env.reset(seed=[3, 4, 5, 6])
+    refs = [oracle.OracleEnv("TSP-v0", **kw) for _ in range(4)]
+    for r, s in zip(refs, (3, 4, 5, 6)):
+        r.reset(seed=s)
+    obs, rew, term, trunc, info = env.step(torch.zeros(4, dtype=torch.int64, device="cuda"))
+    for i, r in enumerate(refs):
+        _, rr, dd, _, inf = r.step(0)
+        assert rr == float(rew[i]) == -10.0 and dd and bool(term[i])
+        assert float(info["solution_cost"][i]) == inf["solution_cost"] == -1.0 and int(info["solved"][i]) == 0
+
+
+def test_state_dict_roundtrip_and_unseeded_reset():
+    ge = _ge()
+    env = ge.make_vec("ShortestPath-v0", 32, n_nodes=16, n_edges=40, obs_mode="flat")
+    env.reset(seed=9)
+    env.random_rollout(7, policy_seed=2)
+    sd = env.state_dict()
+    a = env.sample_random_actions(policy_seed=2).clone()
+    env.step(a)
+    after = env.flat_obs().clone(); rew = env.t["reward"].clone()
+    env.load_state_dict(sd)
+    env.step(a)
+    assert torch.equal(env.flat_obs(), after) and torch.equal(env.t["reward"], rew)
+    # reset(seed=None) moves every slot to its next episode seed (DESIGN.md section 5)
+    seeds0 = env.t["seed"].clone()
+    env.reset()
+    assert torch.equal(env.t["seed"], seeds0 + 32) and int(env.t["episode"].sum()) == 0
