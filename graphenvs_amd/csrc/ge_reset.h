@@ -24,21 +24,33 @@ GE_DEV uint32_t ge_temper(uint32_t y) {
   return y;
 }
 
-// regenerate all 624 words, 64 lanes wide (reads of a chunk complete before its writes)
+// Regenerate all 624 words, 64 lanes wide.  Word i needs the OLD words i, i+1 and, for i < 227, the old word i+397;
+// for i >= 227 the NEW word i-227.  So the state falls into three spans [0,227) [227,454) [454,624) whose words are
+// independent of each other: per span every lane reads its (up to four) operands, the wave synchronises once, and
+// writes -- six ordering points per twist instead of twenty.
 GE_DEV void ge_mt_twist(uint32_t *mt, int lane) {
-  for (int i0 = 0; i0 < GE_MT_N; i0 += GE_WAVE) {
-    int i = i0 + lane;
-    bool ok = i < GE_MT_N;
-    uint32_t a = 0, b = 0, c = 0;
-    if (ok) {
-      int i1 = i + 1; if (i1 == GE_MT_N) i1 = 0;
-      int im = i + GE_MT_M; if (im >= GE_MT_N) im -= GE_MT_N;
-      a = mt[i]; b = mt[i1]; c = mt[im];
+  const int lo[3] = {0, GE_MT_N - GE_MT_M, 2 * (GE_MT_N - GE_MT_M)}, hi[3] = {GE_MT_N - GE_MT_M, 2 * (GE_MT_N - GE_MT_M), GE_MT_N};
+#pragma unroll
+  for (int ph = 0; ph < 3; ph++) {
+    uint32_t a[4], b[4], c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = lo[ph] + lane + 64 * k;
+      a[k] = b[k] = c[k] = 0u;
+      if (i < hi[ph]) {
+        int i1 = i + 1; if (i1 == GE_MT_N) i1 = 0;
+        int im = i + GE_MT_M; if (im >= GE_MT_N) im -= GE_MT_N;
+        a[k] = mt[i]; b[k] = mt[i1]; c[k] = mt[im];
+      }
     }
     ge_wave_sync();
-    if (ok) {
-      uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-      mt[i] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = lo[ph] + lane + 64 * k;
+      if (i < hi[ph]) {
+        const uint32_t y = (a[k] & 0x80000000u) | (b[k] & 0x7fffffffu);
+        mt[i] = c[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
     }
     ge_wave_sync();
   }
@@ -76,6 +88,18 @@ GE_DEV void ge_mt_seed_numpy(uint32_t *mt, uint32_t seed, int lane) {
     mt[0] = prev;
     for (int i = 1; i < GE_MT_N; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; mt[i] = prev; }
   }
+  ge_wave_sync();
+}
+
+
+// copy one pre-seeded MT19937 state (624 words, contiguous in HBM) into LDS: all ten loads of a lane are issued before
+// the first store, so the wave pays one memory round trip instead of ten
+GE_DEV void ge_mt_load(uint32_t *mt, const uint32_t *src, int lane) {
+  uint32_t r[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) { int i = lane + 64 * k; r[k] = i < GE_MT_N ? src[i] : 0u; }
+#pragma unroll
+  for (int k = 0; k < 10; k++) { int i = lane + 64 * k; if (i < GE_MT_N) mt[i] = r[k]; }
   ge_wave_sync();
 }
 
@@ -200,6 +224,9 @@ GE_DEV int ge_sorted_pos(const GeRctx &c, int W, int u, int v) { return c.rowptr
 
 enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
 
+struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; };
+
+
 // Diagnostic build only (-DGE_STAMPS, never shipped): 100 MHz timestamps of slot 0's reset phases.
 #if defined(GE_STAMPS) && !defined(GE_EMU)
 __device__ unsigned long long ge_stamp_buf[32];
@@ -207,8 +234,6 @@ __device__ unsigned long long ge_stamp_buf[32];
 #else
 #define GE_STAMP(k) do { } while (0)
 #endif
-
-struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; };
 
 
 // masked-rejection draws of randint(3, 10) ([np] buffered_bounded_masked_uint32), 64 per round: draw k of the
@@ -219,40 +244,74 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
   int base = 0;
   while (base < total) {
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
-    int p = nppos + lane; bool valid = p < GE_MT_N;
-    uint32_t val = valid ? (ge_temper(mt[p]) & 7u) : 8u;
-    bool acc = valid && val <= 6u;
-    uint64_t bal = ge_ballot(acc);
-    int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
-    int idx = base + rank;
-    if (acc && idx < total) {
-      uint32_t code = 3u + val;
-      if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
-      else if (sink == 1) ((uint8_t *)c.wm)[idx] = (uint8_t)code;
-      else {
-        int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
-        if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
-          c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
+    // all words of the state that are left for this lane are read first (one LDS round trip), then up to ten rounds
+    // of 64 draws run on registers: temper, accept (value & 7) <= 6, rank by ballot, sink
+    uint32_t r[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) { const int p = nppos + lane + 64 * k; r[k] = p < GE_MT_N ? mt[p] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      if (base >= total || nppos >= GE_MT_N) break;  // wave-uniform
+      const int p = nppos + lane; const bool valid = p < GE_MT_N;
+      const uint32_t val = valid ? (ge_temper(r[k]) & 7u) : 8u;
+      const bool acc = valid && val <= 6u;
+      const uint64_t bal = ge_ballot(acc);
+      const int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
+      const int idx = base + rank;
+      if (acc && idx < total) {
+        const uint32_t code = 3u + val;
+        if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
+        else if (sink == 1) ((uint8_t *)c.wm)[idx] = (uint8_t)code;
+        else {
+          const int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
+          if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
+            c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
+          }
         }
       }
+      const int nacc = ge_popc64(bal);
+      if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
+        const int need = total - base - 1;
+        const uint64_t lastb = ge_ballot(acc && rank == need);
+        nppos += ge_ctz64(lastb) + 1;
+        base = total;
+      } else {
+        base += nacc;
+        nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+      }
     }
-    int nacc = ge_popc64(bal);
-    if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
-      int need = total - base - 1;
-      uint64_t lastb = ge_ballot(acc && rank == need);
-      nppos += ge_ctz64(lastb) + 1;
-      base = total;
-    } else {
-      base += nacc;
-      nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
-    }
-    ge_wave_sync();
   }
+  ge_wave_sync();  // rounds only read the state and add into their sink: one ordering point at the end
 }
 
 // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane; result in c.perm
 GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
   const int n = P.n;
+  if (n <= GE_WAVE) {
+    // the permutation lives in one register per lane; a swap is two v_readlane + two selects and the draws of a round
+    // are tempered 64 at a time, so the serial Fisher-Yates chain never waits on LDS
+    uint32_t permv = (uint32_t)lane;
+    int i = n - 1;
+    while (i >= 1) {
+      if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+      const int avail = (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+      const uint32_t dr = lane < avail ? ge_temper(mt[nppos + lane]) : 0u;
+      int k = 0;
+      while (i >= 1 && k < avail) {  // wave-uniform loop
+        const uint32_t j = ge_readlane_u32(dr, k) & ge_mask_below((uint32_t)i);
+        k++;
+        if (j > (uint32_t)i) continue;
+        const uint32_t vi = ge_readlane_u32(permv, i), vj = ge_readlane_u32(permv, (int)j);
+        if (lane == i) permv = vj;
+        if (lane == (int)j) permv = vi;
+        i--;
+      }
+      nppos += k;
+    }
+    if (lane < n) c.perm[lane] = (int)permv;
+    ge_wave_sync();
+    return;
+  }
   for (int v = lane; v < n; v += GE_WAVE) c.perm[v] = v;
   ge_wave_sync();
   int i = n - 1;
@@ -278,8 +337,9 @@ GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, in
 GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane) {
   const int t = P.env_type, n = P.n;
   if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
-  for (int i = lane; i < GE_MT_N; i += GE_WAVE) c.mt2[i] = P.buf.mt_state[((int64_t)env * 2 + 1) * GE_MT_N + i];  // pre-seeded
-  ge_wave_sync();
+  GE_STAMP(20);
+  ge_mt_load(c.mt2, P.buf.mt_state + ((int64_t)env * 2 + 1) * GE_MT_N, lane);  // pre-seeded
+  GE_STAMP(21);
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
   const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
@@ -306,7 +366,9 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
       ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 0);
     } else ge_np_draws(P, c, c.mt2, nppos, t == GE_TSP ? P.m : n, lane, 1);
   }
+  GE_STAMP(22);
   if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane);
+  GE_STAMP(23);
 }
 
 GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
@@ -328,8 +390,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   GE_STAMP(0);
   if (mode != GE_RESET_INJECT) {
     // ---------------------------------------------------------------- topology (python stream)
-    for (int i = lane; i < GE_MT_N; i += GE_WAVE) c.mt[i] = P.buf.mt_state[(int64_t)env * 2 * GE_MT_N + i];  // pre-seeded (ge_k_seed)
-    ge_wave_sync();
+    ge_mt_load(c.mt, P.buf.mt_state + (int64_t)env * 2 * GE_MT_N, lane);  // pre-seeded (ge_k_seed)
     GE_STAMP(1);
     int pypos = GE_MT_N;
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
@@ -364,13 +425,26 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
           const int u = before ? (int)ur : carry_u, v = (int)r;
           bool elig = is_v && u != v && !((c.abits[u * W + (v >> 6)] >> (v & 63)) & 1ull);
           const uint32_t key = elig ? (uint32_t)((u < v ? u : v) << 12 | (u < v ? v : u)) : 0xffffffffu;
+          const uint64_t EL = ge_ballot(elig);  // also the point after which every lane has read the pre-round matrix
+          // A round that cannot reach edge m inserts first and asks questions later: the returning ds_or on the
+          // canonical (min, max) bit tells a lane that the same edge was proposed by another lane of this round;
+          // only then (about one round in four) is the first occurrence worked out exactly.
+          const bool early = cnt + ge_popc64(EL) < m;
+          bool lost = false;
+          if (early && elig) {
+            const int a = u < v ? u : v, b = u < v ? v : u;
+            const unsigned long long bit = 1ull << (b & 63);
+            lost = (atomicOr((unsigned long long *)&c.abits[a * W + (b >> 6)], bit) & bit) != 0;
+          }
           bool dup = false;  // the same edge proposed earlier in this round
-          for (uint64_t rem = ge_ballot(elig); rem;) {
-            const int l0 = ge_ctz64(rem);
-            const uint32_t k0 = ge_shfl_u32(key, l0);
-            const uint64_t same = ge_ballot(elig && key == k0);
-            if (elig && key == k0 && lane != l0) dup = true;
-            rem &= ~same;
+          if (!early || ge_ballot(lost)) {
+            for (uint64_t rem = EL; rem;) {
+              const int l0 = ge_ctz64(rem);
+              const uint32_t k0 = ge_shfl_u32(key, l0);
+              const uint64_t same = ge_ballot(elig && key == k0);
+              if (elig && key == k0 && lane != l0) dup = true;
+              rem &= ~same;
+            }
           }
           bool acc = elig && !dup;
           uint64_t A = ge_ballot(acc);
@@ -390,7 +464,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
             const uint32_t lastr = ge_shfl_u32(r, V ? 63 - (int)__builtin_clzll(V) : 0);
             if (have_u && V) carry_u = (int)lastr;  // with no pick in this round the pending u is carried unchanged
           }
-          if (acc) {
+          if (acc) {  // (an early round already holds the (min, max) bit; setting it again is harmless)
             atomicOr((unsigned long long *)&c.abits[u * W + (v >> 6)], (unsigned long long)(1ull << (v & 63)));
             atomicOr((unsigned long long *)&c.abits[v * W + (u >> 6)], (unsigned long long)(1ull << (u & 63)));
             c.elist[cnt + arank] = (uint32_t)u | ((uint32_t)v << 16);

@@ -185,6 +185,7 @@ GE_DEV uint64_t ge_shfl_u64(uint64_t v, int src) {
 }
 GE_DEV int ge_shfl_i32(int v, int src) { return (int)(int64_t)ge_shfl_u64((uint64_t)(int64_t)v, src); }
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)ge_shfl_u64(v, src); }
+GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx) { return ge_shfl_u32(v, idx); }
 GE_DEV double ge_shfl_f64(double v, int src) { uint64_t u; memcpy(&u, &v, 8); u = ge_shfl_u64(u, src); memcpy(&v, &u, 8); return v; }
 
 GE_DEV uint32_t ge_quad_xchg(uint32_t v, int xr) {
@@ -202,6 +203,7 @@ GE_DEV uint32_t ge_quad_xor2(uint32_t v) { return ge_quad_xchg(v, 2); }
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 GE_DEV void ge_lds_add_f64(double *p, double v) { *p += v; }
 GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return v; }
+GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx);
 GE_DEV int ge_popc64(uint64_t v) { return __builtin_popcountll(v); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }

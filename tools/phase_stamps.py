@@ -19,7 +19,7 @@ L = _lib.bind(C.CDLL(out))
 L.ge_debug_read_stamps.argtypes = [C.c_void_p]
 import graphenvs_amd as ge  # noqa: E402
 
-names = {0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B load+zero", 12: "B bfs forward", 13: "B backward", 14: "B bc/clos/clust", 15: "B pagerank", 16: "B write"}
+names = {0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B load+zero", 12: "B bfs forward", 13: "B backward", 14: "B bc/clos/clust", 15: "B pagerank", 16: "B write", 20: "A1 state load", 21: "A1 draws", 22: "A1 terminals"}
 cfgs = [("ShortestPath-v0", dict(n_nodes=64, n_edges=192), [1, 4096, 65536])]
 if len(sys.argv) > 1 and sys.argv[1] == "all":
     cfgs += [("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), [1, 2048]),
