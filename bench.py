@@ -101,7 +101,7 @@ def main():
         "metric": "env-steps/sec (whole node), ShortestPath-v0 n=64 m=192 batch=65536",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64 bitmask / int32 index (f64 rewards)", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic",
         "config": {"workload": "ShortestPath-v0 n_nodes=64 n_edges=192 weighted, %d env slots per GPU, random valid "
                                "actions on device, same-step autoreset (seed-exact G(n,m)+features on device)" % B,
                    "envs_per_gpu": B, "episodes_finished_per_gpu": episodes, "parallelism": "batch shard x%d, no collective" % world},

@@ -39,7 +39,7 @@ class GeLayout(C.Structure):
     _fields_ = [
         ("F", C.c_int32), ("Fe", C.c_int32), ("A", C.c_int32), ("W", C.c_int32), ("E", C.c_int32),
         ("total_nodes", C.c_int64), ("total_edges", C.c_int64), ("obs_len", C.c_int64),
-        ("reset_lds_bytes", C.c_int64),
+        ("reset_lds_bytes", C.c_int64), ("feat_parts", C.c_int32),
     ]
 
 
@@ -47,7 +47,7 @@ BUFFER_FIELDS = [
     "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "head", "cur_rec", "terminals",
     "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic", "mt_state",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
-    "final_len", "reset_list", "reset_count", "work_list", "work_count",
+    "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
 ]
 
 

@@ -73,6 +73,10 @@ static int derive(const ge_config *cfg, GeParams &P) {
   P.node_id_base = cfg->node_id_base;
   P.edge_row_stride = cfg->edge_row_stride > 0 ? cfg->edge_row_stride : (int64_t)cfg->num_envs * 2 * m;
   P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 256) ? 1 : 0;  // nibble matrix of n*n/2 bytes <= 32 KiB
+  // few slots regenerate per step when graphs are large (long episodes): let up to 8 workgroups share a slot's sources,
+  // as long as the partial-sum scratch stays below 512 MiB
+  P.feat_parts = 1;
+  if (n > 64) { int parts = 8; while (parts > 1 && (int64_t)cfg->num_envs * parts * n * 8 > (512ll << 20)) parts >>= 1; P.feat_parts = parts; }
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
@@ -91,6 +95,7 @@ extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
   out->total_nodes = (int64_t)P.B * P.n; out->total_edges = (int64_t)P.B * P.E;
   out->obs_len = (int64_t)P.n * P.F + (int64_t)P.E * P.Fe + 2 * (int64_t)P.E;
   out->reset_lds_bytes = P.lds.total;
+  out->feat_parts = P.feat_parts;
   return GE_OK;
 }
 
@@ -106,6 +111,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
                         bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
+  if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
   if (P.W == 1 && (!bufs->node_rec || !bufs->cur_rec)) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec and cur_rec");
   P.buf = *bufs;
@@ -198,8 +204,21 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
     GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
     return check_launch("feature kernel (fallback list)");
   }
-  GE_LAUNCH(ge_k_features, fgrid, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode);
-  return check_launch("feature kernel");
+  {
+    int64_t want = (int64_t)fgrid * e->P.feat_parts;
+    if (mode == GE_RESET_QUEUE && want > 4096) want = 4096;  // queue mode: the list is short, workgroups stride over it
+    if (want > 65535 * 16) want = 65535 * 16;
+    GE_LAUNCH(ge_k_features, (int)want, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode);
+  }
+  rc = check_launch("feature kernel");
+  if (rc != GE_OK || e->P.feat_parts == 1) return rc;
+  {
+    size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
+    int64_t items = (int64_t)(mode == GE_RESET_QUEUE ? 4096 : e->P.B) * e->P.n;
+    int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
+    GE_LAUNCH(ge_k_feat_combine, grid, 256, lds, stream, e->P, mode);
+  }
+  return check_launch("feature combine kernel");
 }
 
 extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {

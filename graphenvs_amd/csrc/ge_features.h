@@ -36,7 +36,7 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P) {
 // Any n.  The workgroup has 1..8 waves (whatever fits LDS): the graph is staged once, then every wave runs the
 // level-synchronous Brandes pass for its own sources (s = wave, wave + waves, ...) on private scratch; per-wave
 // betweenness partial sums are combined in wave order, then wave 0 does clustering and pagerank.
-GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
+GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid(), nthreads = ge_bdim();
   const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
   const int n = P.n, W = P.W, E = P.E, F = P.F, t = P.env_type;
@@ -57,7 +57,11 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
   for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
   ge_sync();
   // Brandes betweenness + closeness: one level-synchronous BFS per source, sources dealt round-robin to the waves
-  for (int s = wv; s < n; s += nwaves) {
+  // complete graph on all n nodes (TSP config 3): every pair is adjacent, so no shortest path has an interior node
+  // (betweenness is a sum of zeros) and every BFS has one level of n-1 nodes (closeness (n-1)/(n-1) * (n-1)/(n-1))
+  const bool trivial = P.complete && P.ng == n;
+  if (trivial) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
+  for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
     for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
     ge_wave_sync();
     int d = 0, reach = 1; int64_t tot = 0;
@@ -99,6 +103,14 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
   // betweenness: per-wave partial sums (each in source order) added in wave order
   for (int v = tid; v < n; v += nthreads) { double acc = 0.0; for (int w = 0; w < nwaves; w++) acc += c.bcw0[(w * 4) * n + v]; c.bc[v] = acc; }
   ge_sync();
+  if (nparts > 1) {
+    // several workgroups share this slot's sources (few slots, many CUs): closeness of the own sources is final, the
+    // betweenness partial goes to scratch and ge_k_feat_combine adds the parts in part order
+    for (int v = tid; v < n; v += nthreads) G.feat_scratch[((int64_t)env * nparts + part) * n + v] = c.bc[v];
+    for (int v = tid; v < n; v += nthreads) if ((v % (nwaves * nparts)) / nwaves == part) G.x[(nbase + v) * F + P.nflag + 2] = (float)c.clos[v];
+    ge_sync();
+    if (part != 0) return;  // part 0 also does clustering and pagerank
+  }
   if (wv == 0) {
   if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
   // clustering (directed formula on the symmetric graph) -> coeff[]
@@ -151,7 +163,8 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env) {
   for (int v = lane; v < n; v += GE_WAVE) {
     float *xr = G.x + (nbase + v) * F + P.nflag;
     xr[0] = (float)(2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]));
-    xr[1] = (float)c.bc[v]; xr[2] = (float)c.clos[v]; xr[3] = (float)c.prx[v]; xr[4] = (float)c.coeff[v];
+    if (nparts == 1) { xr[1] = (float)c.bc[v]; xr[2] = (float)c.clos[v]; }
+    xr[3] = (float)c.prx[v]; xr[4] = (float)c.coeff[v];
   }
   }
   ge_sync();
@@ -383,9 +396,32 @@ GE_KERNEL ge_k_features(GeParams P, int mode) {
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
-  for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : (mode == GE_FEAT_LIST ? P.buf.work_list[q] : q);
-    ge_features_generic_env(P, env);
+  const int nparts = (mode == GE_FEAT_LIST) ? 1 : P.feat_parts;
+  for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
+    const int item = q / nparts;
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
+    ge_features_generic_env(P, env, q % nparts, nparts);
+  }
+}
+
+// betweenness of multi-part slots: parts added in part order, then the 1/((n-1)(n-2)) rescale and the float32 cast
+GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
+  int *pre = (int *)ge_dyn_smem();
+  int count = P.B;
+  if (mode == GE_RESET_QUEUE) {
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    ge_sync();
+    count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
+  }
+  const int n = P.n, nparts = P.feat_parts;
+  const double scale = n > 2 ? 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)) : 1.0;
+  for (int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid(); g < (int64_t)count * n; g += (int64_t)ge_gdim() * ge_bdim()) {
+    const int item = (int)(g / n), v = (int)(g % n);
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : item;
+    double acc = 0.0;
+    for (int p = 0; p < nparts; p++) acc += P.buf.feat_scratch[((int64_t)env * nparts + p) * n + v];
+    if (n > 2) acc *= scale;
+    P.buf.x[((int64_t)env * n + v) * P.F + P.nflag + 1] = (float)acc;
   }
 }
 

@@ -44,6 +44,7 @@ struct GeParams {
   int32_t env_type, B, n, m, E, W, F, Fe, A, AW, T, ng, nflag;
   int32_t weighted, parenting, n_dests, is_eval, autoreset, complete;
   int32_t spatial;   // TSP with coordinates and float64 Euclidean weights (sw64 slab)
+  int32_t feat_parts;   // n > 64: workgroups sharing one slot's BFS sources in the feature kernel
   int32_t np_early;  // the numpy wave can produce every weight code without the topology (dense delay matrix fits LDS)
   double n_choices;
   int64_t env_index_base, seed_stride, node_id_base, edge_row_stride;

@@ -244,16 +244,9 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
   int base = 0;
   while (base < total) {
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
-    // all words of the state that are left for this lane are read first (one LDS round trip), then up to ten rounds
-    // of 64 draws run on registers: temper, accept (value & 7) <= 6, rank by ballot, sink
-    uint32_t r[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) { const int p = nppos + lane + 64 * k; r[k] = p < GE_MT_N ? mt[p] : 0u; }
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-      if (base >= total || nppos >= GE_MT_N) break;  // wave-uniform
+    {
       const int p = nppos + lane; const bool valid = p < GE_MT_N;
-      const uint32_t val = valid ? (ge_temper(r[k]) & 7u) : 8u;
+      const uint32_t val = valid ? (ge_temper(mt[p]) & 7u) : 8u;
       const bool acc = valid && val <= 6u;
       const uint64_t bal = ge_ballot(acc);
       const int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
@@ -287,10 +280,11 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
 // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane; result in c.perm
 GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
   const int n = P.n;
-  if (n <= GE_WAVE) {
-    // the permutation lives in one register per lane; a swap is two v_readlane + two selects and the draws of a round
-    // are tempered 64 at a time, so the serial Fisher-Yates chain never waits on LDS
-    uint32_t permv = (uint32_t)lane;
+  if (n <= 4 * GE_WAVE) {
+    // the permutation lives in (up to four) registers per lane: element e sits in lane e % 64, register e / 64.  A swap is
+    // two v_readlane + selects, and the draws of a round are tempered 64 at a time, so the serial Fisher-Yates chain
+    // never waits on LDS
+    uint32_t pv0 = (uint32_t)lane, pv1 = (uint32_t)lane + 64u, pv2 = (uint32_t)lane + 128u, pv3 = (uint32_t)lane + 192u;
     int i = n - 1;
     while (i >= 1) {
       if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
@@ -301,14 +295,19 @@ GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, in
         const uint32_t j = ge_readlane_u32(dr, k) & ge_mask_below((uint32_t)i);
         k++;
         if (j > (uint32_t)i) continue;
-        const uint32_t vi = ge_readlane_u32(permv, i), vj = ge_readlane_u32(permv, (int)j);
-        if (lane == i) permv = vj;
-        if (lane == (int)j) permv = vi;
+        const int si = i >> 6, sj = (int)j >> 6;  // wave-uniform register selectors
+        const uint32_t vi = ge_readlane_u32(si == 0 ? pv0 : si == 1 ? pv1 : si == 2 ? pv2 : pv3, i & 63);
+        const uint32_t vj = ge_readlane_u32(sj == 0 ? pv0 : sj == 1 ? pv1 : sj == 2 ? pv2 : pv3, (int)j & 63);
+        if (lane == (i & 63)) { if (si == 0) pv0 = vj; else if (si == 1) pv1 = vj; else if (si == 2) pv2 = vj; else pv3 = vj; }
+        if (lane == ((int)j & 63)) { if (sj == 0) pv0 = vi; else if (sj == 1) pv1 = vi; else if (sj == 2) pv2 = vi; else pv3 = vi; }
         i--;
       }
       nppos += k;
     }
-    if (lane < n) c.perm[lane] = (int)permv;
+    if (lane < n) c.perm[lane] = (int)pv0;
+    if (lane + 64 < n) c.perm[lane + 64] = (int)pv1;
+    if (lane + 128 < n) c.perm[lane + 128] = (int)pv2;
+    if (lane + 192 < n) c.perm[lane + 192] = (int)pv3;
     ge_wave_sync();
     return;
   }

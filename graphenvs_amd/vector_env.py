@@ -154,6 +154,7 @@ class VectorGraphEnv:
         t["reset_count"] = z(((B + 255) // 256,), torch.int32)
         t["work_list"] = z((B,), torch.int32)
         t["work_count"] = z((4,), torch.int32)
+        t["feat_scratch"] = z((B, lay.feat_parts, n), torch.float64) if lay.feat_parts > 1 else None
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 assert v.dtype == t[k].dtype and v.numel() >= (t[k].numel() if k != "edge_index" else 0), k

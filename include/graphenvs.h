@@ -70,6 +70,7 @@ typedef struct {
   int64_t total_nodes, total_edges;
   int64_t obs_len;             /* flat obs length per env: n*F + E*Fe + 2E (utils.py:87-88) */
   int64_t reset_lds_bytes;     /* dynamic LDS one reset workgroup needs */
+  int32_t feat_parts;          /* workgroups that share one slot in the n > 64 feature kernel (sizes feat_scratch) */
 } ge_layout;
 
 /* Device buffers.  B = num_envs, Nn = B*n, Ne = B*E, W = ceil(n/64).
@@ -119,6 +120,8 @@ typedef struct {
   int32_t *reset_count; /* [ceil(B/256)] finished slots per step workgroup, rewritten by every step    */
   int32_t *work_list;   /* [B]  slots the n<=64 feature fast path hands to the generic feature kernel  */
   int32_t *work_count;  /* [4]  [0] = entries in work_list                                             */
+  double *feat_scratch; /* [B, parts, n] n > 64 only: betweenness partial sums when several workgroups share a slot
+                                 (parts = ge_layout.feat_parts; NULL when parts == 1) */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;

@@ -9,6 +9,7 @@ CONFIGS = {
     "c2": ("ShortestPath-v0", dict(n_nodes=64, n_edges=192), 65536, 200),
     "c3": ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), 16384, 130),
     "c4": ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 16384, 100),
+    "c4long": ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 16384, 700),
     "mis": ("MaxIndependentSet-v0", dict(n_nodes=64, n_edges=192), 65536, 130),
     "ds": ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 65536, 100),
 }

@@ -1,0 +1,19 @@
+"""Diagnostic: build a library variant (-D flags) and run the bench loop with it (for rocprofv3 kernel traces).
+usage: python tools/variant_bench.py "-DFLAG=V ..." [steps]"""
+import ctypes as C, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from graphenvs_amd import _lib
+import graphenvs_amd as ge
+flags = sys.argv[1].split()
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+out = os.path.join(ROOT, "gpurun_out", "libge_variant.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", *flags,
+                       "-I" + _lib.CSRC, os.path.join(_lib.CSRC, "ge_api.hip"), "-o", out])
+L = _lib.bind(C.CDLL(out))
+env = ge.VectorGraphEnv("ShortestPath-v0", 65536, 64, 192, device="cuda", _library=L)
+env.reset(seed=0); env.random_rollout(10, 1); torch.cuda.synchronize()
+t0 = time.perf_counter(); env.random_rollout(steps, 1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(" ".join(flags), f"{65536 * steps / dt / 1e6:.1f} M env-steps/s", flush=True)
