@@ -7,7 +7,9 @@
 #define GE_WAVE 64
 #define GE_MT_N 624
 #define GE_MT_M 397
+#ifndef GE_STEP_BLOCK
 #define GE_STEP_BLOCK 256
+#endif
 #define GE_RESET_THREADS 128
 #ifndef GE_RESET_WAVES_PER_SIMD
 #define GE_RESET_WAVES_PER_SIMD 6  // 24 waves / CU = 12 two-wave workgroups: one round for the ~2 700 resets of a headline step

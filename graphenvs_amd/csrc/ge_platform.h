@@ -35,6 +35,10 @@ GE_DEV uint32_t ge_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov
 // fire-and-forget LDS adds (ds_add_u32 / ds_add_f64, no return value, nothing to wait for)
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 GE_DEV void ge_lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+// every outstanding load has returned (s_waitcnt vmcnt(0)): placed where that is already true, in front of a block of
+// stores, it keeps the compiler's conservative per-register waits at control-flow joins from landing between the
+// stores, where they would wait for store acknowledgements
+GE_DEV void ge_wait_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 GE_DEV uint64_t ge_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 GE_DEV int ge_shfl_i32(int v, int src) { return __shfl(v, src, 64); }
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }

@@ -328,12 +328,16 @@ GE_DEV int ge_nth_set_bit(uint64_t word, uint32_t r) {
   return ge_ctz64(word);
 }
 
-// Headline fast path: ShortestPath / LongestPath(parenting 0,1) with n <= 64.  One u64 per node set, three
-// dependent rounds of loads (slot state -> bit rows of head and action -> one weight byte), optional fused
-// sampling of the random policy (SAMPLE) so a rollout step is a single launch.
+// Headline fast path: ShortestPath / LongestPath(parenting 0,1) with n <= 64.  One u64 per node set.  The kernel is
+// three phases per slot: (A) every load -- the coalesced slot state, then ONE 16-byte gather for the record of the
+// chosen node; (B) the transition in registers; (C) every store.  No load is issued after the first store: vmcnt
+// counts loads and stores in order, so a late load (or a register reused at a control-flow join) would make the wave
+// wait for its stores to be acknowledged in the middle of the kernel.  Optional fused sampling of the random policy
+// (SAMPLE) so a rollout step is a single launch.
 #ifndef GE_ABL
-#define GE_ABL 0  // diagnostic ablation bits (tools/ablate_step.py); 0 in the shipped library
+#define GE_ABL 0  // diagnostic ablation bits (tools/step_variants.py, results are wrong by construction); 0 when shipped
 #endif
+#define GE_ON(bit) (!(GE_ABL & (bit)))  // 1 x flag, 2 bool-mask bytes, 4 gather, 8 policy, 16 state stores, 64 output stores
 template <bool SAMPLE>
 GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actions_out, uint64_t policy_seed) {
   const ge_buffers &G = P.buf;
@@ -347,36 +351,38 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
   bool wrote_mask = false;
   bool want_reset = false;
   if (i < P.B) {
-    // round 1: slot state (coalesced)
+    // ---- phase A, round 1: slot state (coalesced), including what only a finishing slot needs
     const uint64_t mb = G.mask_bits[i];
     const uint8_t st = G.status[i];
     const int head = G.head[i];
     const int dest = G.terminals[2 * (int64_t)i + 1];
-    double cost = G.cost[i];
-    uint64_t vis = G.node_bits[i];
+    const double cost0 = G.cost[i];
+    const uint64_t vis0 = G.node_bits[i];
     const int64_t ts = G.tstep[i];
     const int len0 = G.counters[2 * i + 1];
     const ulonglong2 crec = ((const ulonglong2 *)G.cur_rec)[i];
+    const double heur0 = G.heuristic[i];
+    const uint32_t seed0 = P.autoreset ? G.seed[i] : 0u;
+    const int64_t ep0 = P.autoreset ? G.episode[i] : 0;
     int64_t a64;
     if (SAMPLE) {
-      uint32_t cnt = (uint32_t)ge_popc64(mb);
+      const uint32_t cnt = (uint32_t)ge_popc64(mb);
       if (!cnt || st == 1) a64 = -1;
+      else if (!GE_ON(8)) a64 = ge_ctz64(mb);
       else {
         uint64_t z = ge_mix64(policy_seed + (uint64_t)(P.env_index_base + i) * 0x9E3779B97F4A7C15ull + (uint64_t)ts * 0xD1B54A32D192ED03ull);
         a64 = ge_nth_set_bit(mb, (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32));
       }
-      actions_out[i] = a64;
     } else {
       a64 = actions_in[i];
     }
     const bool in_range = a64 >= 0 && a64 < (int64_t)n;
     const int a = in_range ? (int)a64 : 0;
-    // round 2: ONE 16-byte gather -- the record of the chosen node (its bit row and its packed weight codes).
-    // The head's record travels in the coalesced slot state (cur_rec), so the reward needs no row_ptr / scode gather.
+    // ---- phase A, round 2: the record of the chosen node (its bit row and its packed weight codes).  The head's
+    // record travels in the slot state (cur_rec), so the reward needs no row_ptr / scode gather.
     const int64_t nbase = (int64_t)i * n;
-    const uint64_t adjH = (GE_ABL & 4) ? (mb | 2) : crec.x;
-    const ulonglong2 arec = (GE_ABL & 4) ? make_ulonglong2(mb * 3, 0x3333333333333333ull) : ((const ulonglong2 *)G.node_rec)[nbase + a];
-    const uint64_t adjA = arec.x;
+    const uint64_t adjH = crec.x;
+    const ulonglong2 arec = GE_ON(4) ? ((const ulonglong2 *)G.node_rec)[nbase + a] : make_ulonglong2(mb * 3, 0x3333333333333333ull);
     const bool nbr = (adjH >> a) & 1ull;
     const int rank = ge_popc64(adjH & ((1ull << a) - 1ull));
     int code = (int)((crec.y >> (4 * (rank & 15))) & 15ull);
@@ -386,60 +392,72 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
       code = G.scode[(int64_t)i * P.E + pos];
     }
 
-    double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
+    // ---- phase B: the transition, in registers (shortest_path.py:101-141, longest_path.py:121-196)
+    double reward = 0.0, cost = cost0;
+    int done = 0, solved = -1, invalid = 0;
+    bool acted = false, moved = false;
+    uint64_t vis = vis0, nm = mb;
     if (st == 0 && a64 != -1) {
       const bool mbit = in_range && ((mb >> a) & 1ull);
-      const bool vis_a = (vis >> a) & 1ull;
+      const bool vis_a = (vis0 >> a) & 1ull;
       if (!mbit || (lp && P.parenting >= 1 && (!nbr || vis_a))) invalid = 1;
       else {
         acted = true;
         const double wgt = nbr ? ge_wlut(code) : 0.0;
         if (lp) { reward = wgt; cost -= wgt; } else { reward = -wgt; cost -= reward; }
-        G.cost[i] = cost;
         if (lp && (!nbr || vis_a)) { done = 1; solved = 0; reward = -2.0 * n; }  // longest_path.py:169-173
         else {
+          moved = true;
           if (a == dest) { done = 1; solved = 1; }
-          G.head[i] = a;
-          if (!(GE_ABL & 1)) G.x[(nbase + a) * F + 0] = 1.f;
-          vis |= 1ull << a;
-          G.node_bits[i] = vis;
-          ((ulonglong2 *)G.cur_rec)[i] = arec;
-          const uint64_t nm = open_mask ? mb : (adjA & ~vis);
-          stage[tid] = nm;
-          wrote_mask = !open_mask;
+          vis = vis0 | (1ull << a);
+          nm = open_mask ? mb : (arec.x & ~vis);
           if (!done && !nm) { done = 1; solved = 0; reward = lp ? -2.0 * n : -(double)n; }
         }
       }
     }
-    G.reward[i] = reward;
-    G.terminated[i] = (uint8_t)done;
-    G.invalid[i] = (uint8_t)invalid;
-    G.solved[i] = (int8_t)solved;
-    if (acted) {
-      const int len = len0 + 1;
-      G.counters[2 * i + 1] = len;
+    const bool fin = acted && done;
+    want_reset = fin && P.autoreset;
+    wrote_mask = moved && !open_mask && !want_reset;
+    stage[tid] = nm;
+
+    // ---- phase C: stores only
+    ge_wait_loads();
+    if (GE_ON(64)) {
+      if (SAMPLE) actions_out[i] = a64;
+      G.reward[i] = reward;
+      G.terminated[i] = (uint8_t)done;
+      G.invalid[i] = (uint8_t)invalid;
+      G.solved[i] = (int8_t)solved;
+    }
+    if (acted && GE_ON(16)) {
+      G.cost[i] = cost;
+      G.counters[2 * i + 1] = len0 + 1;
       G.tstep[i] = ts + 1;
-      if (done) {
-        G.final_cost[i] = cost;
-        G.final_heur[i] = G.heuristic[i];
-        G.final_len[i] = len;
-        if (P.autoreset) {
-          want_reset = true;
-          G.seed[i] = G.seed[i] + (uint32_t)P.seed_stride;
-          G.episode[i] = G.episode[i] + 1;
-          G.status[i] = 2;
-          wrote_mask = false;
-        } else {
-          G.status[i] = 1;
-        }
+    }
+    if (moved) {
+      if (GE_ON(1)) G.x[(nbase + a) * F + 0] = 1.f;
+      if (GE_ON(16)) {
+        G.head[i] = a;
+        G.node_bits[i] = vis;
+        ((ulonglong2 *)G.cur_rec)[i] = arec;
       }
     }
-    if (wrote_mask) G.mask_bits[i] = stage[tid];
+    if (wrote_mask && GE_ON(16)) G.mask_bits[i] = nm;
+    if (fin) {
+      G.final_cost[i] = cost;
+      G.final_heur[i] = heur0;
+      G.final_len[i] = len0 + 1;
+      G.status[i] = P.autoreset ? 2 : 1;
+      if (P.autoreset) {
+        G.seed[i] = seed0 + (uint32_t)P.seed_stride;
+        G.episode[i] = ep0 + 1;
+      }
+    }
   }
   flag[tid] = wrote_mask ? 1 : 0;
   ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
-  if (nb <= 0 || (GE_ABL & 2)) return;
+  if (nb <= 0 || !GE_ON(2)) return;
   uint8_t *out = G.mask + (int64_t)i0 * n;
   if ((n & 7) == 0) {
     const int groups = nb * (n >> 3);

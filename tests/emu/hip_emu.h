@@ -165,6 +165,7 @@ GE_DEV void ge_sync() { ge_emu::barrier(); }
 GE_DEV void ge_wave_sync() { ge_emu::wave_rendezvous(0); }
 GE_DEV void ge_quad_sync() { ge_emu::Block &b = ge_emu::blk(); b.fib[b.cur].waiting = 3; ge_emu::yield_to_sched(); }
 
+GE_DEV void ge_wait_loads() {}
 GE_DEV uint64_t ge_ballot(bool p) {
   using namespace ge_emu;
   int g = wave_rendezvous(p ? 1 : 0);
