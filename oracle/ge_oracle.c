@@ -132,6 +132,7 @@ struct oge_env {
   int *terms; int n_targets; /* terms[0]=src, terms[1..n_targets] */
   double cost64; float cost32;
   double heuristic;
+  int mc_failed;               /* multicast: info['solution_cost'] stays -1 unless the episode is solved */
   int64_t edge_taken_cnt; int nodes_taken_cnt;
   uint8_t *alive; int n_alive; /* residual graph for parenting >= 2 */
   uint8_t *dtaken;             /* densest: python set nodes_taken */
@@ -143,7 +144,8 @@ struct oge_env {
   uint8_t *tmp8;
 };
 
-static int node_flag_count(int t) { return t == OGE_TSP ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : 2); }
+static int node_flag_count(int t) { return (t == OGE_TSP || t == OGE_MULTICAST_ROUTING) ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : 2); }
+static int edge_actions(int t) { return t == OGE_STEINER_TREE || t == OGE_MULTICAST_ROUTING; }
 
 int oge_num_node_features(const oge_env *e) { return e->F; }
 int oge_num_edge_features(const oge_env *e) { return e->Fe; }
@@ -158,8 +160,8 @@ oge_env *oge_create(const oge_cfg *cfg) {
   e->n = n; e->m = m; e->E = 2 * m;
   e->nflag = node_flag_count(cfg->env_type);
   e->F = e->nflag + 5;                                   /* utils.py:32-73 (+5 :72) */
-  e->Fe = (cfg->env_type == OGE_STEINER_TREE) ? 2 : 1;   /* utils.py:37-40 */
-  e->A = (cfg->env_type == OGE_STEINER_TREE) ? e->E : n; /* steiner_tree.py:117 */
+  e->Fe = edge_actions(cfg->env_type) ? 2 : 1;   /* utils.py:37-40, 53-56 */
+  e->A = edge_actions(cfg->env_type) ? e->E : n; /* steiner_tree.py:117, multicast_routing.py:155 */
   /* densest_subgraph.py:38-39: n_choices = n_nodes // e (float floor division) */
   e->n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;
   size_t nn = (size_t)n * n;
@@ -397,7 +399,7 @@ static double dijkstra(oge_env *e, int s, int t) {
       if (d < e->sigma[u]) e->sigma[u] = d;
     }
   }
-  return e->sigma[t];
+  return t >= 0 ? e->sigma[t] : 0.0;
 }
 
 /* steiner_tree.py:80-81: sum(delay of nx.minimum_spanning_edges) = Kruskal order = ascending weights,
@@ -495,7 +497,129 @@ static void compute_mask(oge_env *e) {
     case OGE_MAX_INDEPENDENT_SET: /* max_independent_set.py:92-100 */
       for (int v = 0; v < n; v++) e->mask[v] = (e->x[v * F + 1] == 0.0f);
       break;
+    case OGE_MULTICAST_ROUTING: { /* multicast_routing.py:155-188 */
+      const int E = e->E, par = e->cfg.parenting;
+      for (int p = 0; p < E; p++) e->mask[p] = !(e->ef[2 * p + 1] > 0.5f);
+      if (par >= 2)
+        for (int p = 0; p < E; p++) {
+          int u = (int)e->links[2 * p], v = (int)e->links[2 * p + 1];
+          if (e->x[u * F + 0] < 0.5f || e->x[v * F + 0] > 0.5f) e->mask[p] = 0;
+        }
+      if (par >= 3) { /* one edge per reachable node: the tree edge that gives it the smallest distance (float32) */
+        memset(e->tmp8, 0, n);
+        for (int p = 0; p < E; p++) if (e->mask[p]) e->tmp8[e->links[2 * p + 1]] = 1; /* np.unique(Vs) */
+        memset(e->mask, 0, E);
+        for (int v = 0; v < n; v++) {
+          if (!e->tmp8[v]) continue;
+          int best = -1; float bd = INFINITY;
+          for (int p = 0; p < E; p++) { /* np.argmin over all edges, inf where not (edge into v from the tree): first minimum */
+            if ((int)e->links[2 * p + 1] != v || !(e->x[e->links[2 * p] * F + 0] > 0.5f)) continue;
+            float d = e->x[e->links[2 * p] * F + 3] + e->ef[2 * p + 0];
+            if (best < 0 || d < bd) { best = p; bd = d; }
+          }
+          e->mask[best] = 1;
+        }
+      }
+      break;
+    }
   }
+}
+
+/* ---- CPython 3.10 set of 2-tuples of small non-negative ints: iteration order (Objects/setobject.c, tupleobject.c).
+ * tuple hash = xxHash-style mix of the element hashes (hash(int) = int); table of 8 slots growing to the power of two
+ * above 4*used when fill*5 >= mask*3; probing = the slot, 9 linear probes, then i = i*5 + 1 + (perturb >>= 5). */
+typedef struct { int64_t key; uint64_t hash; } pyset_entry; /* key = u * 65536 + v, -1 = empty */
+typedef struct { pyset_entry *tab; size_t mask; size_t used; } pyset;
+static uint64_t pytuple2_hash(uint64_t a, uint64_t b) {
+  const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+  uint64_t acc = P5;
+  acc += a * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+  acc += b * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+  acc += 2ULL ^ (P5 ^ 3527539ULL);
+  return acc == (uint64_t)-1 ? 1546275796ULL : acc;
+}
+static void pyset_insert_clean(pyset_entry *tab, size_t mask, int64_t key, uint64_t hash) {
+  size_t perturb = hash, i = (size_t)hash & mask;
+  for (;;) {
+    if (tab[i].key < 0) { tab[i].key = key; tab[i].hash = hash; return; }
+    if (i + 9 <= mask) for (size_t j = 1; j <= 9; j++) if (tab[i + j].key < 0) { tab[i + j].key = key; tab[i + j].hash = hash; return; }
+    perturb >>= 5; i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+static void pyset_add(pyset *so, int64_t key, uint64_t hash) {
+  size_t mask = so->mask, perturb = hash, i = (size_t)hash & mask;
+  pyset_entry *slot = NULL;
+  for (;;) {
+    size_t probes = (i + 9 <= mask) ? 9 : 0;
+    for (size_t j = 0; j <= probes && !slot; j++) {
+      if (so->tab[i + j].key < 0) slot = &so->tab[i + j];
+      else if (so->tab[i + j].hash == hash && so->tab[i + j].key == key) return; /* already present */
+    }
+    if (slot) break;
+    perturb >>= 5; i = (i * 5 + 1 + perturb) & mask;
+  }
+  slot->key = key; slot->hash = hash; so->used++;
+  if (so->used * 5 < mask * 3) return; /* fill == used: nothing is ever removed */
+  size_t minused = so->used > 50000 ? so->used * 2 : so->used * 4, newsize = 8;
+  while (newsize <= minused) newsize <<= 1;
+  pyset_entry *nt = (pyset_entry *)malloc(newsize * sizeof(pyset_entry));
+  for (size_t k = 0; k < newsize; k++) nt[k].key = -1;
+  for (size_t k = 0; k <= mask; k++) if (so->tab[k].key >= 0) pyset_insert_clean(nt, newsize - 1, so->tab[k].key, so->tab[k].hash);
+  free(so->tab); so->tab = nt; so->mask = newsize - 1;
+}
+/* test hook: iteration order of set() after adding the pairs (u[i], v[i]) in order; returns the count */
+int oge_pyset_order(const int32_t *u, const int32_t *v, int count, int32_t *out_u, int32_t *out_v) {
+  pyset so; so.mask = 7; so.used = 0; so.tab = (pyset_entry *)malloc(8 * sizeof(pyset_entry));
+  for (int k = 0; k < 8; k++) so.tab[k].key = -1;
+  for (int i = 0; i < count; i++) pyset_add(&so, (int64_t)u[i] * 65536 + v[i], pytuple2_hash((uint64_t)u[i], (uint64_t)v[i]));
+  int o = 0;
+  for (size_t k = 0; k <= so.mask; k++) if (so.tab[k].key >= 0) { out_u[o] = (int32_t)(so.tab[k].key >> 16); out_v[o] = (int32_t)(so.tab[k].key & 65535); o++; }
+  free(so.tab);
+  return o;
+}
+static double pyset_sum_path_edges(oge_env *e, const int *pred) {
+  int n = e->n;
+  int32_t *pu = (int32_t *)malloc((size_t)n * (e->n_targets + 1) * sizeof(int32_t)), *pv = (int32_t *)malloc((size_t)n * (e->n_targets + 1) * sizeof(int32_t));
+  int cnt = 0;
+  for (int i = 1; i <= e->n_targets; i++) { /* for d in dests: for u, v in zip(path[:-1], path[1:]) */
+    int len = 0;
+    for (int v = e->terms[i]; v != 0; v = pred[v]) e->q[len++] = v;
+    int u = 0;
+    for (int k = len - 1; k >= 0; k--) { pu[cnt] = u; pv[cnt] = e->q[k]; cnt++; u = e->q[k]; }
+  }
+  int32_t *ou = (int32_t *)malloc((size_t)(cnt + 1) * sizeof(int32_t)), *ov = (int32_t *)malloc((size_t)(cnt + 1) * sizeof(int32_t));
+  int k = oge_pyset_order(pu, pv, cnt, ou, ov);
+  double s = 0.0;
+  for (int i = 0; i < k; i++) s += e->uw[ou[i] * n + ov[i]];
+  free(pu); free(pv); free(ou); free(ov);
+  return s;
+}
+
+/* multicast_routing.py:108-118: total delay of the union of the shortest paths source -> destinations.
+ * [nx] _dijkstra_multisource keeps, for every node, the path of the LAST strict improvement; the fringe is a
+ * heap of (distance, push counter, node), so among equal-distance predecessors the one popped first wins.  The heap
+ * order is reproduced without a heap: a node's live entry is its latest push (pushes happen only on strict
+ * improvement), so the next pop is the unfinished node with the smallest (seen, counter of its latest push). */
+static double multicast_baseline(oge_env *e) {
+  int n = e->n;
+  double *seen = e->sigma; int *cnt = e->dist, *pred = e->stk; uint8_t *fin = e->tmp8;
+  for (int v = 0; v < n; v++) { seen[v] = INFINITY; cnt[v] = -1; pred[v] = -1; fin[v] = 0; }
+  int counter = 0;
+  seen[0] = 0.0; cnt[0] = counter++;
+  for (;;) {
+    int v = -1;
+    for (int u = 0; u < n; u++)
+      if (!fin[u] && cnt[u] >= 0 && (v < 0 || seen[u] < seen[v] || (seen[u] == seen[v] && cnt[u] < cnt[v]))) v = u;
+    if (v < 0) break;
+    fin[v] = 1;
+    for (int k = e->row_ptr[v]; k < e->row_ptr[v + 1]; k++) { /* G._adj[v] in insertion order */
+      int u = e->col[k]; double d = seen[v] + e->w64[k];
+      if (fin[u]) continue;
+      if (cnt[u] < 0 || d < seen[u]) { seen[u] = d; cnt[u] = counter++; pred[u] = v; }
+    }
+  }
+  /* the python set of (u, v) tuples is summed in its iteration order: CPython set of 2-tuples of small ints */
+  return pyset_sum_path_edges(e, pred);
 }
 
 /* ------------------------------------------------------------------ reset */
@@ -600,6 +724,26 @@ int oge_reset(oge_env *e, int64_t seed) {
     build_directed(e);
     for (int p = 0; p < e->E; p++) e->ef[p] = 1.f;
     e->heuristic = e->cfg.is_eval_env ? -1.0 : 0.0; e->head = -1;
+  } else if (t == OGE_MULTICAST_ROUTING) { /* multicast_routing.py:76-152 */
+    delay_matrix_weights(e);
+    build_directed(e);
+    /* :98 np.random.choice(np.arange(1, n), size=k, replace=False) = arange(1, n)[permutation(n - 1)[:k]] */
+    for (int i = 0; i < n - 1; i++) e->q[i] = i;
+    for (int i = n - 2; i >= 1; i--) { int j = (int)np_interval(e->np, (uint32_t)i); int tt = e->q[i]; e->q[i] = e->q[j]; e->q[j] = tt; }
+    e->src = 0; e->terms[0] = 0; e->n_targets = e->cfg.n_dests;
+    for (int i = 0; i < e->cfg.n_dests; i++) e->terms[1 + i] = e->q[i] + 1;
+    dijkstra(e, 0, -1); /* :101-103 shortest_path_length from the source to every node */
+    double ft = -INFINITY, fn = -INFINITY;
+    for (int i = 1; i <= e->n_targets; i++) if (e->sigma[e->terms[i]] > ft) ft = e->sigma[e->terms[i]];
+    for (int v = 0; v < n; v++) if (e->sigma[v] > fn) fn = e->sigma[v];
+    double max_distance = np_rand(e->np) * (fn - ft) + ft; /* :106 */
+    e->heuristic = e->cfg.is_eval_env ? multicast_baseline(e) : 0.0; /* :108-118 */
+    e->x[0 * F + 0] = 1.f;
+    for (int i = 1; i <= e->n_targets; i++) e->x[e->terms[i] * F + 1] = 1.f;
+    for (int v = 0; v < n; v++) { e->x[v * F + 2] = (float)max_distance; e->x[v * F + 3] = -1.f; }
+    e->x[0 * F + 3] = 0.f;
+    e->head = 0; e->mc_failed = 1;
+    for (int p = 0; p < e->E; p++) { e->ef[2 * p] = (float)e->w64[p]; e->ef[2 * p + 1] = 0.f; }
   } else { /* MIS: max_independent_set.py:53-60 */
     double *cost = e->sigma;
     for (int v = 0; v < n; v++) cost[v] = e->cfg.weighted ? (double)np_randint(e->np, 3, 10) / 10.0 : 1.0;
@@ -692,6 +836,32 @@ int oge_step(oge_env *e, int64_t action, double *reward, int32_t *done, int32_t 
       *reward = (double)r;
       return OGE_OK;
     }
+    case OGE_MULTICAST_ROUTING: { /* multicast_routing.py:191-266 */
+      if (action < 0 || action >= e->E || !e->mask[action]) return OGE_INVALID_ACTION;
+      const int u = (int)e->links[2 * action], v = (int)e->links[2 * action + 1];
+      const double fail = -2.0 * n * e->cfg.n_dests;
+      float r = -e->ef[2 * action + 0];
+      e->cost32 -= r; /* python int 0, then numpy float32 accumulation */
+      e->mc_failed = 1;
+      if (e->x[u * F + 0] == 0.f || e->x[v * F + 0] == 1.f) { /* :211-217 (parenting 1 only): nothing changes */
+        *done = 1; *solved = 0; *reward = fail; compute_mask(e); return OGE_OK;
+      }
+      e->x[v * F + 0] = 1.f; e->ef[2 * action + 1] = 1.f;
+      e->x[v * F + 3] = e->x[u * F + 3] + e->ef[2 * action + 0]; /* float32 + float32 */
+      if (e->x[v * F + 1] == 1.f) {
+        if (e->x[v * F + 3] > e->x[v * F + 2] + 1e-4f) { /* :230: float32 + python float stays float32 */
+          *done = 1; *solved = 0; *reward = fail; compute_mask(e); return OGE_OK;
+        }
+        r += 1; /* float32 */
+      }
+      int left = 0;
+      for (int w = 0; w < n; w++) if (e->x[w * F + 0] < 1e-5f && e->x[w * F + 1] > (float)(1 - 1e-5)) left++;
+      compute_mask(e);
+      *reward = (double)r;
+      if (left == 0) { *done = 1; *solved = 1; e->mc_failed = 0; }
+      else if (mask_sum(e) == 0) { *done = 1; *solved = 0; *reward = fail; }
+      return OGE_OK;
+    }
     case OGE_TSP: { /* tsp.py:201-258 */
       if (action == e->start && e->head == e->start) { /* :203-211 */
         *done = 1; *solved = 0; *reward = -(double)n; e->cost64 = -1.0; compute_mask(e); return OGE_OK;
@@ -758,6 +928,7 @@ void oge_get_mask(const oge_env *e, uint8_t *mask) { memcpy(mask, e->mask, e->A)
 void oge_get_features64(const oge_env *e, double *sf) { memcpy(sf, e->sf64, (size_t)e->n * 5 * sizeof(double)); }
 double oge_solution_cost(const oge_env *e) {
   int t = e->cfg.env_type;
+  if (t == OGE_MULTICAST_ROUTING) return e->mc_failed ? -1.0 : (double)e->cost32; /* multicast_routing.py:203,262 */
   return (t == OGE_STEINER_TREE || t == OGE_MAX_INDEPENDENT_SET) ? (double)e->cost32 : e->cost64;
 }
 double oge_heuristic_solution(const oge_env *e) { return e->heuristic; }

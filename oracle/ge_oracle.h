@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { OGE_SHORTEST_PATH = 0, OGE_LONGEST_PATH = 1, OGE_STEINER_TREE = 2, OGE_TSP = 3,
-       OGE_DENSEST_SUBGRAPH = 4, OGE_MAX_INDEPENDENT_SET = 5 };
+       OGE_DENSEST_SUBGRAPH = 4, OGE_MAX_INDEPENDENT_SET = 5, OGE_MULTICAST_ROUTING = 6 };
 
 typedef struct {
   int32_t env_type;
@@ -28,7 +28,7 @@ typedef struct {
   int32_t n_edges;
   int32_t weighted;
   int32_t parenting;
-  int32_t n_dests;     /* SteinerTree only */
+  int32_t n_dests;     /* SteinerTree, MulticastRouting */
   int32_t spatial;     /* TSP only */
   int32_t is_eval_env;
   double n_choices;    /* DensestSubgraph only; <0 -> n_nodes // e (reference default) */
@@ -54,7 +54,7 @@ int oge_step(oge_env *e, int64_t action, double *reward, int32_t *done, int32_t 
 int oge_num_node_features(const oge_env *e);  /* F  */
 int oge_num_edge_features(const oge_env *e);  /* Fe */
 int oge_num_directed_edges(const oge_env *e); /* E = 2m */
-int oge_mask_size(const oge_env *e);          /* n, or 2m for SteinerTree */
+int oge_mask_size(const oge_env *e);          /* n, or 2m for SteinerTree / MulticastRouting */
 int oge_obs_size(const oge_env *e);           /* n*F + E*Fe + 2E */
 
 /* state readers (copy out) */
@@ -87,6 +87,9 @@ int64_t oge_policy_pick(const uint8_t *mask, int n, uint64_t policy_seed, uint64
 int64_t oge_rollout(const oge_cfg *cfg, int64_t first_seed, int64_t seed_stride, int32_t n_envs,
                     int32_t n_steps, uint64_t policy_seed, int32_t n_threads,
                     double *out_sum_reward, int64_t *out_episodes, double *out_reset_seconds);
+
+/* iteration order of a CPython 3.10 set after adding the int pairs (u[i], v[i]) in order (multicast baseline sums a set) */
+int oge_pyset_order(const int32_t *u, const int32_t *v, int count, int32_t *out_u, int32_t *out_v);
 
 /* raw MT19937 access, for pinning the two generators themselves */
 void oge_mt_py_seed(uint32_t *state625, uint32_t seed);

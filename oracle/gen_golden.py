@@ -60,6 +60,16 @@ CASES = {
     "sp_n512_m1536": ("ShortestPath-v0", dict(n_nodes=512, n_edges=1536), [0]),
     "mis_n200_m600": ("MaxIndependentSet-v0", dict(n_nodes=200, n_edges=600), [0]),
     "ds_n100_m300_p1": ("DensestSubgraph-v0", dict(n_nodes=100, n_edges=300, parenting=1), [0, 1]),
+    # MulticastRouting (multicast_routing.py)
+    "mc_n10_m20_p4": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20), list(range(10))),
+    "mc_n10_m20_p3_d2": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20, n_dests=2, parenting=3), list(range(6))),
+    "mc_n10_m20_p2": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20, parenting=2), list(range(8))),
+    "mc_n10_m20_p1": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20, parenting=1), list(range(8))),
+    "mc_n12_auto_edges_p4_unweighted": ("MulticastRouting-v0", dict(n_nodes=12, weighted=False), list(range(4))),
+    "mc_n10_m20_p4_eval": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20, is_eval_env=True), list(range(8))),
+    "mc_n64_m192_p4_d5": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), list(range(4))),
+    "mc_n64_m192_p2_d8": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=8, parenting=2), list(range(3))),
+    "mc_n200_m600_p4_d6": ("MulticastRouting-v0", dict(n_nodes=200, n_edges=600, n_dests=6), [0]),
 }
 
 POLICIES = ("first", "rand")
@@ -83,6 +93,8 @@ def terminals_of(env, env_id):
         return [int(env.src)] + [int(d) for d in env.dests]
     if env_id == "TSP-v0":
         return [0]
+    if env_id == "MulticastRouting-v0":
+        return [int(env.src)] + [int(d) for d in env.dests]
     return []
 
 

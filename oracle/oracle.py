@@ -19,6 +19,7 @@ ENV_TYPES = {
     "TSP-v0": 3,
     "DensestSubgraph-v0": 4,
     "MaxIndependentSet-v0": 5,
+    "MulticastRouting-v0": 6,
 }
 
 
@@ -74,6 +75,8 @@ def lib():
         L.oge_rollout.restype = i64
         L.oge_rollout.argtypes = [C.POINTER(OgeCfg), i64, i64, i32, i32, C.c_uint64, i32,
                                   C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
+        L.oge_pyset_order.restype = C.c_int
+        L.oge_pyset_order.argtypes = [vp, vp, C.c_int, vp, vp]
         L.oge_mt_py_seed.argtypes = [vp, C.c_uint32]
         L.oge_mt_np_seed.argtypes = [vp, C.c_uint32]
         L.oge_mt_next.restype = C.c_uint32
@@ -82,9 +85,14 @@ def lib():
     return _lib
 
 
-def make_cfg(env_id, n_nodes, n_edges, weighted=None, parenting=-1, n_dests=3, spatial=False,
+def make_cfg(env_id, n_nodes, n_edges=-1, weighted=None, parenting=None, n_dests=3, spatial=False,
              is_eval_env=False, n_choices=-1, **_ignored) -> OgeCfg:
     t = ENV_TYPES[env_id]
+    if parenting is None:
+        parenting = 4 if t == 6 else -1  # multicast_routing.py:31
+    if n_edges == -1:
+        assert t == 6, "n_edges is required"
+        n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # multicast_routing.py:53-54
     if weighted is None:
         weighted = (t != 4)  # DensestSubgraph defaults to weighted=False (densest_subgraph.py:25)
     return OgeCfg(t, n_nodes, n_edges, int(bool(weighted)), int(parenting), int(n_dests),
@@ -202,3 +210,12 @@ def mt_stream(kind, seed, count):
     L = lib()
     (L.oge_mt_py_seed if kind == "py" else L.oge_mt_np_seed)(st.ctypes.data, seed)
     return np.array([L.oge_mt_next(st.ctypes.data) for _ in range(count)], dtype=np.uint32)
+
+
+def pyset_order(pairs):
+    """iteration order of set(pairs) built by adding the int pairs one by one (CPython 3.10 set emulation in the oracle)"""
+    u = np.ascontiguousarray([p[0] for p in pairs], dtype=np.int32)
+    v = np.ascontiguousarray([p[1] for p in pairs], dtype=np.int32)
+    ou, ov = np.zeros(len(pairs) + 1, dtype=np.int32), np.zeros(len(pairs) + 1, dtype=np.int32)
+    k = lib().oge_pyset_order(u.ctypes.data, v.ctypes.data, len(pairs), ou.ctypes.data, ov.ctypes.data)
+    return [(int(a), int(b)) for a, b in zip(ou[:k], ov[:k])]

@@ -98,3 +98,15 @@ def test_policy_pick_is_uniform_and_deterministic():
 def test_rollout_counts_transitions():
     out = oracle.rollout("ShortestPath-v0", n_envs=8, n_steps=50, n_nodes=10, n_edges=20, n_threads=2)
     assert out["transitions"] == 400 and out["episodes"] > 8
+
+
+def test_pyset_order_matches_cpython():
+    """the multicast baseline sums a python set of (u, v) tuples: the oracle's CPython set emulation against set() itself"""
+    rng = random.Random(5)
+    for _ in range(200):
+        n = rng.choice([5, 10, 64, 200, 512])
+        pairs = [(rng.randrange(n), rng.randrange(n)) for _ in range(rng.randint(0, min(600, n * 3)))]
+        s = set()
+        for p in pairs:
+            s.add(p)
+        assert list(s) == oracle.pyset_order(pairs)
