@@ -22,6 +22,7 @@ ENV_TYPES = {
     "TSP-v0": 3,
     "DensestSubgraph-v0": 4,
     "MaxIndependentSet-v0": 5,
+    "MulticastRouting-v0": 6,
 }
 
 
@@ -48,6 +49,7 @@ BUFFER_FIELDS = [
     "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic", "mt_state",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
     "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
+    "node_aux",
 ]
 
 

@@ -37,7 +37,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (!cfg) return fail(GE_E_BADARG, "null config");
   memset(&P, 0, sizeof(P));
   const int t = cfg->env_type, n = cfg->n_nodes, m = cfg->n_edges;
-  if (t < GE_SHORTEST_PATH || t > GE_MAX_INDEPENDENT_SET) return fail(GE_E_BADARG, "unknown env_type");
+  if (t < GE_SHORTEST_PATH || t > GE_MULTICAST_ROUTING) return fail(GE_E_BADARG, "unknown env_type");
   if (cfg->num_envs < 1) return fail(GE_E_BADARG, "num_envs must be >= 1");
   if (n < 3 || n > 4095) return fail(GE_E_BADARG, "n_nodes must be in [3, 4095]");
   const int ng = (t == GE_DENSEST_SUBGRAPH) ? n - 1 : n;  // densest_subgraph.py:59
@@ -52,18 +52,20 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (t == GE_DENSEST_SUBGRAPH && cfg->parenting != 0 && cfg->parenting != 1) return fail(GE_E_BADARG, "Parenting must be 0 or 1 (densest_subgraph.py:28)");
   if (t == GE_DENSEST_SUBGRAPH && cfg->weighted) return fail(GE_E_BADARG, "Weighted graphs not supported for this env (densest_subgraph.py:29)");
   if (t == GE_TSP && cfg->spatial && !cfg->weighted) return fail(GE_E_BADARG, "Spatial TSP must be weighted (tsp.py:27)");
-  if (t == GE_STEINER_TREE && (cfg->n_dests < 1 || cfg->n_dests > n - 1)) return fail(GE_E_BADARG, "n_dests must be in [1, n_nodes-1]");
+  if ((t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING) && (cfg->n_dests < 1 || cfg->n_dests > n - 1)) return fail(GE_E_BADARG, "n_dests must be in [1, n_nodes-1]");
+  if (t == GE_MULTICAST_ROUTING && (cfg->parenting < 1 || cfg->parenting > 4)) return fail(GE_E_BADARG, "Invalid parenting type (multicast_routing.py:34-35)");
   // not built yet
   if (t == GE_TSP && cfg->spatial && n > 512) return fail(GE_E_UNSUPPORTED, "spatial TSP is built for n_nodes <= 512");
   if ((t == GE_LONGEST_PATH || t == GE_TSP) && cfg->parenting >= 2 && n > 64 * GE_MAXW) return fail(GE_E_UNSUPPORTED, "parenting >= 2 is built for n_nodes <= 512");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
-  P.nflag = (t == GE_TSP) ? 4 : (t == GE_DENSEST_SUBGRAPH ? 1 : 2);  // utils.py:32-73
+  const bool edge_env = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
+  P.nflag = (t == GE_TSP || t == GE_MULTICAST_ROUTING) ? 4 : (t == GE_DENSEST_SUBGRAPH ? 1 : 2);  // utils.py:32-73
   P.F = P.nflag + 5;
-  P.Fe = (t == GE_STEINER_TREE) ? 2 : 1;
-  P.A = (t == GE_STEINER_TREE) ? P.E : n;  // steiner_tree.py:117
+  P.Fe = edge_env ? 2 : 1;
+  P.A = edge_env ? P.E : n;  // steiner_tree.py:117, multicast_routing.py:155-157
   P.AW = (P.A + 63) / 64;
-  P.T = (t == GE_STEINER_TREE) ? (cfg->n_dests + 1 > 2 ? cfg->n_dests + 1 : 2) : 2;
+  P.T = edge_env ? (cfg->n_dests + 1 > 2 ? cfg->n_dests + 1 : 2) : 2;
   P.weighted = cfg->weighted ? 1 : 0; P.parenting = cfg->parenting; P.n_dests = cfg->n_dests;
   P.spatial = (t == GE_TSP && cfg->spatial) ? 1 : 0;
   P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset ? 1 : 0;
@@ -111,6 +113,8 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
                         bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
+  if (P.env_type == GE_MULTICAST_ROUTING && P.parenting == 2 && !bufs->rev_edge) return fail(GE_E_BADARG, "MulticastRouting parenting 2 needs rev_edge");
+  if (P.env_type == GE_MULTICAST_ROUTING && P.parenting >= 3 && !bufs->node_aux) return fail(GE_E_BADARG, "MulticastRouting parenting >= 3 needs node_aux");
   if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
   if (P.W == 1 && (!bufs->node_rec || !bufs->cur_rec)) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec and cur_rec");

@@ -278,8 +278,9 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
 }
 
 // np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane; result in c.perm
-GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
-  const int n = P.n;
+// legacy numpy permutation(pn) into c.perm (np.random.choice(pn, k, replace=False) is its first k entries)
+GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane, int pn) {
+  const int n = pn;
   if (n <= 4 * GE_WAVE) {
     // the permutation lives in (up to four) registers per lane: element e sits in lane e % 64, register e / 64.  A swap is
     // two v_readlane + selects, and the draws of a round are tempered 64 at a time, so the serial Fisher-Yates chain
@@ -331,6 +332,164 @@ GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, in
   }
 }
 
+// [nx] dijkstra from `src` to every node: least fixpoint of d[u] = min_v fl(d[v] + w(v,u)) (float addition is monotone, so
+// the distances do not depend on the relaxation order); Jacobi sweeps in LDS.  Distances are left in c.sigma.
+GE_DEV void ge_dijkstra_wave(const GeRctx &c, int n, int src, int lane) {
+  for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = (v == src) ? 0.0 : __builtin_inf();
+  ge_wave_sync();
+  for (int it = 0; it < n; it++) {
+    uint64_t any = 0;
+    for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+      int v = k0 + lane; bool ch = false;
+      if (v < n) {
+        double best = c.sigma[v];
+        for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
+          double d = c.sigma[c.colw[k] >> 4] + ge_wlut(c.colw[k] & 15);
+          if (d < best) { best = d; ch = true; }
+        }
+        c.delta[v] = best;
+      }
+      any |= ge_ballot(ch);
+    }
+    ge_wave_sync();
+    for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = c.delta[v];
+    ge_wave_sync();
+    if (!any) break;
+  }
+}
+
+// CPython tuple hash of (a, b), small non-negative ints (Objects/tupleobject.c, xxHash-style; hash(int) = int)
+GE_DEV uint64_t ge_pytuple2_hash(uint64_t a, uint64_t b) {
+  const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
+  uint64_t acc = P5;
+  acc += a * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+  acc += b * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+  acc += 2ull ^ (P5 ^ 3527539ull);
+  return acc == ~0ull ? 1546275796ull : acc;
+}
+
+// multicast_routing.py:108-118 (is_eval_env): total delay of the union of the shortest paths source -> destinations.
+// [nx] _dijkstra_multisource keeps for every node the path of its LAST strict improvement and pops a heap of
+// (distance, push counter, node): the pop order is reproduced without a heap (a node's live entry is its latest push),
+// and the python set of (u, v) tuples the edges are collected in is summed in CPython's set iteration order
+// (Objects/setobject.c: 8 slots growing to the power of two above 4*used at fill*5 >= mask*3; slot, 9 linear probes,
+// then i*5 + 1 + (perturb >>= 5)).  The set tables live in the slot's x rows, which are rewritten afterwards.
+GE_DEV double ge_multicast_baseline(const GeParams &P, const GeRctx &c, int env, int lane) {
+  const int n = P.n, W = P.W;
+  double *seen = c.sigma; int *cnt = c.dist, *pred = c.fill; uint64_t *fin = c.bits;
+  for (int v = lane; v < n; v += GE_WAVE) { seen[v] = __builtin_inf(); cnt[v] = -1; pred[v] = -1; }
+  if (lane < W) fin[lane] = 0ull;
+  ge_wave_sync();
+  if (lane == 0) { seen[0] = 0.0; cnt[0] = 0; }
+  int counter = 1;
+  ge_wave_sync();
+  for (;;) {
+    double bs = __builtin_inf(); int bc = 0x7fffffff, bv = -1;
+    for (int v = lane; v < n; v += GE_WAVE)
+      if (cnt[v] >= 0 && !((fin[v >> 6] >> (v & 63)) & 1ull) && (bv < 0 || seen[v] < bs || (seen[v] == bs && cnt[v] < bc))) { bs = seen[v]; bc = cnt[v]; bv = v; }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double os = ge_shfl_f64(bs, lane ^ off); const int oc = ge_shfl_i32(bc, lane ^ off), ov = ge_shfl_i32(bv, lane ^ off);
+      if (ov >= 0 && (bv < 0 || os < bs || (os == bs && oc < bc))) { bs = os; bc = oc; bv = ov; }
+    }
+    if (bv < 0) break;
+    const int v = bv;
+    ge_wave_sync();
+    if (lane == 0) fin[v >> 6] |= 1ull << (v & 63);
+    ge_wave_sync();
+    for (int k0 = c.rowptr[v]; k0 < c.rowptr[v + 1]; k0 += GE_WAVE) {  // G._adj[v] in insertion order
+      const int k = k0 + lane; const bool valid = k < c.rowptr[v + 1];
+      const int u = valid ? (c.colw[k] >> 4) : 0;
+      const double d = valid ? bs + ge_wlut(c.colw[k] & 15) : 0.0;
+      const bool imp = valid && !((fin[u >> 6] >> (u & 63)) & 1ull) && (cnt[u] < 0 || d < seen[u]);
+      const uint64_t Bm = ge_ballot(imp);
+      if (imp) { seen[u] = d; cnt[u] = counter + ge_popc64(Bm & ((1ull << lane) - 1ull)); pred[u] = v; }
+      counter += ge_popc64(Bm);
+      ge_wave_sync();
+    }
+  }
+  double total = 0.0;
+  if (lane == 0) {
+    uint32_t *slab = (uint32_t *)(P.buf.x + (int64_t)env * n * P.F);
+    const uint32_t cap = (uint32_t)(n * P.F), EMPTY = 0xffffffffu;
+    uint32_t *tab = slab; uint32_t mask = 7, used = 0; bool low = true;
+    for (uint32_t i = 0; i < 8; i++) tab[i] = EMPTY;
+    int *stack = (int *)c.elist;  // u32[m], m >= n - 1; free once the CSR is built
+    for (int di = 1; di <= P.n_dests; di++) {  // for d in dests: for u, v in zip(path[:-1], path[1:]): add((u, v))
+      int len = 0;
+      for (int v = c.perm[di]; v != 0; v = pred[v]) stack[len++] = v;
+      int u = 0;
+      for (int q = len - 1; q >= 0; q--) {
+        const int v = stack[q];
+        const uint32_t key = ((uint32_t)u << 16) | (uint32_t)v;
+        const uint64_t h = ge_pytuple2_hash((uint64_t)u, (uint64_t)v);
+        u = v;
+        uint64_t perturb = h; uint32_t i = (uint32_t)h & mask; int slot = -1; bool present = false;
+        for (;;) {
+          const uint32_t probes = (i + 9 <= mask) ? 9u : 0u;
+          for (uint32_t j = 0; j <= probes && slot < 0 && !present; j++) {
+            if (tab[i + j] == EMPTY) slot = (int)(i + j);
+            else if (tab[i + j] == key) present = true;
+          }
+          if (slot >= 0 || present) break;
+          perturb >>= 5; i = (uint32_t)((uint64_t)i * 5 + 1 + perturb) & mask;
+        }
+        if (present) continue;
+        tab[slot] = key; used++;
+        if ((uint64_t)used * 5 < (uint64_t)mask * 3) continue;
+        uint32_t newsize = 8; while (newsize <= used * 4) newsize <<= 1;
+        uint32_t *nt = low ? slab + (cap - newsize) : slab;  // old + new tables fit the slab (used <= n - 1)
+        for (uint32_t q2 = 0; q2 < newsize; q2++) nt[q2] = EMPTY;
+        for (uint32_t q2 = 0; q2 <= mask; q2++) {
+          const uint32_t kk = tab[q2];
+          if (kk == EMPTY) continue;
+          const uint64_t hh = ge_pytuple2_hash((uint64_t)(kk >> 16), (uint64_t)(kk & 0xffffu));
+          uint64_t pt = hh; uint32_t ii = (uint32_t)hh & (newsize - 1);
+          for (;;) {
+            int sl = -1;
+            if (nt[ii] == EMPTY) sl = (int)ii;
+            else if (ii + 9 <= newsize - 1) for (uint32_t j = 1; j <= 9 && sl < 0; j++) if (nt[ii + j] == EMPTY) sl = (int)(ii + j);
+            if (sl >= 0) { nt[sl] = kk; break; }
+            pt >>= 5; ii = (uint32_t)((uint64_t)ii * 5 + 1 + pt) & (newsize - 1);
+          }
+        }
+        tab = nt; mask = newsize - 1; low = !low;
+      }
+    }
+    for (uint32_t q2 = 0; q2 <= mask; q2++) {  // sum([G[u][v]['delay'] for u, v in all_path_edges])
+      const uint32_t kk = tab[q2];
+      if (kk == EMPTY) continue;
+      const int u = (int)(kk >> 16), v = (int)(kk & 0xffffu);
+      for (int k = c.rowptr[u]; k < c.rowptr[u + 1]; k++) if ((c.colw[k] >> 4) == v) { total += ge_wlut(c.colw[k] & 15); break; }
+    }
+  }
+  total = ge_shfl_f64(total, 0);
+  ge_wave_sync();
+  return total;
+}
+
+// MulticastRouting tail of the numpy stream (multicast_routing.py:98,106): dests = arange(1, n)[permutation(n - 1)[:k]],
+// then ONE rand() for max_distance.  Leaves perm[0] = 0 (the source), perm[1..k] = dests and the rand in misc[0..1].
+GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
+  ge_np_terminals(P, c, mt, nppos, lane, P.n - 1);
+  const int k = P.n_dests;
+  for (int base = ((k - 1) / GE_WAVE) * GE_WAVE; base >= 0; base -= GE_WAVE) {  // shift up by one slot, +1 on the values
+    const int idx = base + lane;
+    const int val = idx < k ? c.perm[idx] : 0;
+    ge_wave_sync();
+    if (idx < k) c.perm[idx + 1] = val + 1;
+    ge_wave_sync();
+  }
+  if (lane == 0) c.perm[0] = 0;
+  uint32_t r2[2];
+  for (int q = 0; q < 2; q++) {
+    if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+    r2[q] = ge_temper(mt[nppos]); nppos++;
+  }
+  // [np] mt19937_next_double: (a >> 5, b >> 6) -> 53 bits
+  if (lane == 0) *(double *)c.misc = ((double)(int32_t)(r2[0] >> 5) * 67108864.0 + (double)(int32_t)(r2[1] >> 6)) / 9007199254740992.0;
+  ge_wave_sync();
+}
+
 // The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
 // depend on the topology runs beside the python-stream graph sampling of the first wave.
 GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane) {
@@ -341,7 +500,7 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
   GE_STAMP(21);
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
-  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   if (P.spatial) {  // tsp.py:81-83: x, y = np.random.rand() * 10 per node; rand() = two 32-bit draws, no rejection
     uint32_t *raw = c.wm; double *xy = (double *)(c.wm + 4 * n);
     for (int p0 = 0; p0 < 4 * n; p0 += GE_WAVE) {
@@ -366,7 +525,8 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
     } else ge_np_draws(P, c, c.mt2, nppos, t == GE_TSP ? P.m : n, lane, 1);
   }
   GE_STAMP(22);
-  if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane);
+  if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
+  else if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane, n);
   GE_STAMP(23);
 }
 
@@ -377,6 +537,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   const int wv = ge_tid() >> 6;
   const int n = P.n, ng = P.ng, W = P.W, m = P.m, E = P.E, F = P.F, T = P.T;
   const int t = P.env_type;
+  const bool path_like_t = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   GeRctx c = ge_carve(P);
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   int src = 0, dest = -1;
@@ -561,7 +722,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   if (mode != GE_RESET_INJECT) {
     for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
     ge_wave_sync();
-    const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+    const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
     if (P.weighted && path_like && P.np_early) {  // delay[u, v], u < v, from the nibble matrix the numpy wave filled
       for (int idx = lane; idx < E; idx += GE_WAVE) {
         int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
@@ -594,7 +755,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     } else if (P.weighted && path_like) {  // n too large for the dense matrix: draw now, codes land by rank
       int nppos = GE_MT_N;
       ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 2);
-      ge_np_terminals(P, c, c.mt2, nppos, lane);
+      if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
+      else ge_np_terminals(P, c, c.mt2, nppos, lane, n);
     }
     ge_wave_sync();
     for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
@@ -603,14 +765,14 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     }
     ge_wave_sync();
     GE_STAMP(5);
-    if (path_like) { src = c.perm[0]; dest = c.perm[1]; }
+    if (path_like) { src = c.perm[0]; dest = c.perm[1]; }  // multicast: perm[0] = 0 (multicast_routing.py:97)
   } else {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
       c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)(c.colw[idx] & 15);
     }
     ge_wave_sync();
-    if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) {
+    if (path_like_t) {
       for (int k = lane; k < T; k += GE_WAVE) c.perm[k] = inj.terminals[(int64_t)env * T + k];
       ge_wave_sync();
       src = c.perm[0]; dest = c.perm[1];
@@ -624,28 +786,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   if (mode != GE_RESET_INJECT && P.is_eval) {
     const double kNaN = __builtin_nan("");
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || (t == GE_STEINER_TREE && P.n_dests == 1)) {
-      // [nx] dijkstra: least fixpoint of d[u] = min_v fl(d[v] + w(v,u)); Jacobi sweeps in LDS
-      for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = (v == src) ? 0.0 : __builtin_inf();
-      ge_wave_sync();
-      for (int it = 0; it < n; it++) {
-        uint64_t any = 0;
-        for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
-          int v = k0 + lane; bool ch = false;
-          if (v < n) {
-            double best = c.sigma[v];
-            for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
-              double d = c.sigma[c.colw[k] >> 4] + ge_wlut(c.colw[k] & 15);
-              if (d < best) { best = d; ch = true; }
-            }
-            c.delta[v] = best;
-          }
-          any |= ge_ballot(ch);
-        }
-        ge_wave_sync();
-        for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = c.delta[v];
-        ge_wave_sync();
-        if (!any) break;
-      }
+      ge_dijkstra_wave(c, n, src, lane);
       double d = c.sigma[dest];
       heuristic = (t == GE_LONGEST_PATH) ? -d : d;
       ge_wave_sync();
@@ -677,7 +818,25 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       ge_wave_sync();
     } else if (t == GE_DENSEST_SUBGRAPH) heuristic = -1.0;             // densest_subgraph.py:85-88
     else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : kNaN;  // greedy MIS not built
+    else if (t == GE_MULTICAST_ROUTING) heuristic = 0.0;                 // computed below, after the delay bound
     else heuristic = kNaN;                                              // Kou / Christofides not built
+  }
+
+  // ------------------------------------------------------------------ multicast: delay bound (multicast_routing.py:101-106)
+  double max_distance = 0.0;
+  if (mode != GE_RESET_INJECT && t == GE_MULTICAST_ROUTING) {
+    ge_dijkstra_wave(c, n, 0, lane);
+    double fn = -__builtin_inf(), ft = -__builtin_inf();  // farthest node, farthest destination
+    for (int v = lane; v < n; v += GE_WAVE) { const double d = c.sigma[v]; if (d > fn) fn = d; }
+    for (int k = 1 + lane; k <= P.n_dests; k += GE_WAVE) { const double d = c.sigma[c.perm[k]]; if (d > ft) ft = d; }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double a = ge_shfl_f64(fn, lane ^ off), b = ge_shfl_f64(ft, lane ^ off);
+      if (a > fn) fn = a;
+      if (b > ft) ft = b;
+    }
+    max_distance = *(const double *)c.misc * (fn - ft) + ft;  // np.random.rand() * (farthest_node - farthest_target) + farthest_target
+    ge_wave_sync();
+    if (P.is_eval) heuristic = ge_multicast_baseline(P, c, env, lane);
   }
 
   GE_STAMP(9);
@@ -688,7 +847,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   if (lane < W) {
     uint64_t tb = 0;
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) { if ((dest >> 6) == lane) tb = 1ull << (dest & 63); }
-    else if (t == GE_STEINER_TREE) for (int k = 1; k <= P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
+    else if (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING) for (int k = 1; k <= P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
     tbits[lane] = tb;
   }
   ge_wave_sync();
@@ -703,6 +862,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       else if (t == GE_LONGEST_PATH) val = (col == 0) ? (v == src ? 1.f : 0.f) : (is_t ? 1.f : ((P.parenting == 0 && v == src) ? 2.f : 0.f));
       else if (t == GE_TSP) val = (col == 1 && v == 0) ? 1.f : ((P.spatial && col >= 2) ? (float)((const double *)(c.wm + 4 * n))[2 * v + (col - 2)] : 0.f);
       else if (t == GE_MAX_INDEPENDENT_SET) val = (col == 0) ? (float)ge_wlut(c.fill[v]) : 0.f;
+      else if (t == GE_MULTICAST_ROUTING)  // HAS_MSG, IS_TARGET, MAX_DISTANCE, DISTANCE_FROM_SOURCE (multicast_routing.py:124-129)
+        val = (col == 0) ? (v == src ? 1.f : 0.f) : (col == 1) ? (is_t ? 1.f : 0.f) : (col == 2) ? (float)max_distance : (v == src ? 0.f : -1.f);
       G.x[(nbase + v) * F + col] = val;
     }
   }
@@ -731,7 +892,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
   // first mask (reset() -> info['mask'])
   const int A = P.A, AW = P.AW;
-  const bool node_started = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE);
+  const bool node_started = path_like_t;
   uint64_t *prune = c.bits + 4 * W;  // parenting >= 2: nodes that stay selectable
   if (lane < W) prune[lane] = ~0ull;
   ge_wave_sync();
@@ -764,7 +925,9 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;
     uint64_t full = (hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull);
     if (t == GE_SHORTEST_PATH || (t == GE_LONGEST_PATH && P.parenting != 0) || t == GE_TSP) mb = c.abits[src * W + w] & prune[w];
-    else if (t == GE_STEINER_TREE) {  // edges leaving src: steiner_tree.py:116-120
+    else if (t == GE_STEINER_TREE || (t == GE_MULTICAST_ROUTING && P.parenting >= 2)) {  // edges leaving src: steiner_tree.py:116-120;
+      // multicast_routing.py:155-186: parenting 2 the same; parenting >= 3 keeps, per outside node, its best tree edge, and
+      // with only the source in the tree that is the one edge from the source
       int a = c.rowptr[src], b = c.rowptr[src + 1]; mb = 0;
       int l2 = a > lo ? a : lo, h2 = b < hi ? b : hi;
       if (h2 > l2) mb = ((h2 - l2 == 64) ? ~0ull : ((1ull << (h2 - l2)) - 1ull)) << (l2 - lo);
@@ -779,6 +942,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (node_started && (src >> 6) == w) nb = 1ull << (src & 63);
     G.node_bits[(int64_t)env * W + w] = nb;
     G.target_bits[(int64_t)env * W + w] = tbits[w];
+  }
+  if (G.node_aux) {  // multicast parenting >= 3: the selectable edge into every node
+    for (int v = lane; v < n; v += GE_WAVE) G.node_aux[nbase + v] = -1;
+    ge_wave_sync();
+    for (int k = c.rowptr[src] + lane; k < c.rowptr[src + 1]; k += GE_WAVE) G.node_aux[nbase + (c.colw[k] >> 4)] = k;
   }
   for (int k = lane; k < T; k += GE_WAVE) G.terminals[(int64_t)env * T + k] = (t == GE_TSP) ? 0 : ((t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : c.perm[k]);
   if (lane == 0) {

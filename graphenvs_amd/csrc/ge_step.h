@@ -67,7 +67,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
   const int i = i0 + tid;
   const int n = P.n, W = P.W, F = P.F, A = P.A, AW = P.AW, t = P.env_type;
   uint64_t *stage = (uint64_t *)ge_dyn_smem();  // [blockDim][W] new node masks (node-action envs)
-  const bool edge_mask = (t == GE_STEINER_TREE);
+  const bool edge_mask = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   bool wrote_mask = false;  // this slot's node mask changed and sits in `stage`
 
   bool want_reset = false;
@@ -77,6 +77,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
     int64_t a64 = actions[i];
     uint8_t st = G.status[i];
     double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
+    bool cost_hidden = false;  // multicast: info['solution_cost'] stays -1 unless the episode is solved
     if (st != 0 || a64 == -1) {
       // frozen slot (finished, autoreset off) or explicit no-op: nothing moves
     } else {
@@ -211,6 +212,70 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
           }
           break;
         }
+        case GE_MULTICAST_ROUTING: {  // multicast_routing.py:191-266
+          if (!mbit) { invalid = 1; break; }
+          acted = true; cost_hidden = true;
+          const int64_t ebase = (int64_t)i * P.E;
+          const int32_t *rp = G.row_ptr + (int64_t)i * (n + 1);
+          const uint16_t e = G.colw[ebase + a];
+          const int v = e >> 4;
+          const int u = (int)(G.edge_index[ebase + a] - P.node_id_base - nbase);
+          const float delay = (float)ge_wlut(e & 15);
+          float r = -delay;
+          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;  // numpy float32 accumulator
+          const double fail = -2.0 * n * P.n_dests;
+          uint64_t *nbits = G.node_bits + (int64_t)i * W;
+          const bool has_u = (nbits[u >> 6] >> (u & 63)) & 1ull, has_v = (nbits[v >> 6] >> (v & 63)) & 1ull;
+          if (!has_u || has_v) { done = 1; solved = 0; reward = fail; break; }  // :211-217 (parenting 1 only): nothing changes
+          nbits[v >> 6] |= 1ull << (v & 63);
+          G.x[(nbase + v) * F + 0] = 1.f;
+          G.edge_attr[(ebase + a) * 2 + 1] = 1.f;
+          const float dv = G.x[(nbase + u) * F + 3] + delay;  // float32 + float32
+          G.x[(nbase + v) * F + 3] = dv;
+          uint64_t *mb = G.mask_bits + (int64_t)i * AW;
+          uint8_t *mby = G.mask + (int64_t)i * A;
+          // the mask after the move (also returned by the failure exits below)
+          if (P.parenting == 1) { mb[a >> 6] &= ~(1ull << (a & 63)); mby[a] = 0; }  // not taken
+          else if (P.parenting == 2) {  // tree -> outside edges
+            for (int k = rp[v]; k < rp[v + 1]; k++) {
+              const int w = G.colw[ebase + k] >> 4;
+              if (!((nbits[w >> 6] >> (w & 63)) & 1ull)) { mb[k >> 6] |= 1ull << (k & 63); mby[k] = 1; }
+              const int rk = G.rev_edge[ebase + k];
+              mb[rk >> 6] &= ~(1ull << (rk & 63)); mby[rk] = 0;
+            }
+          } else {  // per outside node the tree edge of smallest float32 distance, first index on ties (np.argmin)
+            int32_t *best = G.node_aux + nbase;
+            mb[a >> 6] &= ~(1ull << (a & 63)); mby[a] = 0;  // a == best[v]
+            best[v] = -1;
+            for (int k = rp[v]; k < rp[v + 1]; k++) {
+              const uint16_t ek = G.colw[ebase + k];
+              const int w = ek >> 4;
+              if ((nbits[w >> 6] >> (w & 63)) & 1ull) continue;
+              const float dn = dv + (float)ge_wlut(ek & 15);
+              const int cur = best[w];
+              bool take = cur < 0;
+              if (!take) {
+                const int uc = (int)(G.edge_index[ebase + cur] - P.node_id_base - nbase);
+                const float dc = G.x[(nbase + uc) * F + 3] + (float)ge_wlut(G.colw[ebase + cur] & 15);
+                take = dn < dc || (dn == dc && k < cur);
+                if (take) { mb[cur >> 6] &= ~(1ull << (cur & 63)); mby[cur] = 0; }
+              }
+              if (take) { best[w] = k; mb[k >> 6] |= 1ull << (k & 63); mby[k] = 1; }
+            }
+          }
+          const bool is_t = (G.target_bits[(int64_t)i * W + (v >> 6)] >> (v & 63)) & 1ull;
+          if (is_t) {
+            if (dv > G.x[(nbase + v) * F + 2] + 1e-4f) { done = 1; solved = 0; reward = fail; break; }  // :230, float32
+            r += 1.f;
+          }
+          reward = (double)r;
+          uint64_t missing = 0, any = 0;
+          for (int w = 0; w < W; w++) missing |= G.target_bits[(int64_t)i * W + w] & ~nbits[w];
+          for (int w = 0; w < AW; w++) any |= mb[w];
+          if (!missing) { done = 1; solved = 1; cost_hidden = false; }
+          else if (!any) { done = 1; solved = 0; reward = fail; }
+          break;
+        }
         case GE_DENSEST_SUBGRAPH: {
           bool taken_a = in_range && ((G.node_bits[(int64_t)i * W + (a >> 6)] >> (a & 63)) & 1ull);
           if (!mbit || taken_a) { invalid = 1; break; }
@@ -270,7 +335,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
       if (!(t == GE_DENSEST_SUBGRAPH || t == GE_TSP)) { len += 1; G.counters[i * 2 + 1] = len; }
       G.tstep[i] = G.tstep[i] + 1;
       if (done) {
-        G.final_cost[i] = G.cost[i];
+        G.final_cost[i] = cost_hidden ? -1.0 : G.cost[i];
         G.final_heur[i] = G.heuristic[i];
         G.final_len[i] = len;
         if (P.autoreset) {

@@ -8,11 +8,11 @@ import torch
 
 from .vector_env import VectorGraphEnv
 
-_F32_REWARD = ("SteinerTree-v0", "MaxIndependentSet-v0")  # steiner_tree.py:137, max_independent_set.py:109
+_F32_REWARD = ("SteinerTree-v0", "MaxIndependentSet-v0", "MulticastRouting-v0")  # steiner_tree.py:137, max_independent_set.py:109, multicast_routing.py:200
 
 
 class GraphEnv:
-    def __init__(self, env_id, n_nodes, n_edges, device="cuda", _library=None, **kwargs):
+    def __init__(self, env_id, n_nodes, n_edges=-1, device="cuda", _library=None, **kwargs):
         self.env_id = env_id
         self._v = VectorGraphEnv(env_id, 1, n_nodes, n_edges, device=device, autoreset=False, obs_mode="flat",
                                  _library=_library, **kwargs)
@@ -41,7 +41,10 @@ class GraphEnv:
         solved = int(self._np(info["solved"])[0])
         if solved >= 0:
             out["solved"] = bool(solved)
-        if done or self.env_id == "LongestPath-v0":
+        if self.env_id == "MulticastRouting-v0":  # both keys on every step; the cost is -1 unless solved (multicast_routing.py:202-203,262)
+            out["solution_cost"] = np.float32(self._np(self._v.t["final_cost"])[0]) if done else -1
+            out["heuristic_solution"] = float(self._np(self._v.t["heuristic"])[0])
+        elif done or self.env_id == "LongestPath-v0":
             cost = self._np(self._v.t["cost"])[0]
             out["solution_cost"] = np.float32(cost) if self.env_id in _F32_REWARD else np.float64(cost)
             out["heuristic_solution"] = float(self._np(self._v.t["heuristic"])[0])
@@ -56,5 +59,5 @@ class GraphEnv:
 
 
 def make(env_id, **kwargs):
-    """gym.make(id, **kwargs) for the six hot-path ids (graph_envs/__init__.py:9-56)."""
+    """gym.make(id, **kwargs) for the hot-path ids (graph_envs/__init__.py:9-56)."""
     return GraphEnv(env_id, **kwargs)

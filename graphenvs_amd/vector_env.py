@@ -25,10 +25,11 @@ _DEFAULTS = {
     "TSP-v0": dict(weighted=True, return_graph_obs=False, parenting=-1, spatial=False, is_eval_env=False),
     "DensestSubgraph-v0": dict(weighted=False, n_choices=-1, return_graph_obs=False, is_eval_env=False, parenting=-1),
     "MaxIndependentSet-v0": dict(weighted=True, return_graph_obs=False, is_eval_env=False),
+    "MulticastRouting-v0": dict(n_dests=3, weighted=True, max_distance=-1, parenting=4, is_eval_env=False),
 }
 
 
-def normalize_kwargs(env_id, n_nodes, n_edges, **kwargs):
+def normalize_kwargs(env_id, n_nodes, n_edges=-1, **kwargs):
     """Apply the reference constructors' defaults and asserts (same messages)."""
     if env_id not in _DEFAULTS:
         raise KeyError(f"unknown env id {env_id!r}; hot-path ids are {ENV_IDS}")
@@ -50,8 +51,11 @@ def normalize_kwargs(env_id, n_nodes, n_edges, **kwargs):
     if env_id == "DensestSubgraph-v0":
         assert kw["parenting"] in [0, 1], "Parenting must be 0 or 1"  # densest_subgraph.py:28
         assert kw["weighted"] == False, "Weighted graphs not supported for this env"  # noqa: E712
-    if env_id in ("LongestPath-v0", "DensestSubgraph-v0") and n_edges == -1:
-        n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # longest_path.py:41-42
+    if env_id == "MulticastRouting-v0" and kw["parenting"] not in [1, 2, 3, 4]:
+        raise ValueError("Invalid parenting type")  # multicast_routing.py:34-35
+    if env_id in ("LongestPath-v0", "DensestSubgraph-v0", "MulticastRouting-v0") and n_edges == -1:
+        n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # longest_path.py:41-42, multicast_routing.py:53-54
+    assert n_edges != -1, f"{env_id} needs n_edges"
     if env_id == "DensestSubgraph-v0" and kw["n_choices"] == -1:
         kw["n_choices"] = float(n_nodes // np.exp(1))  # densest_subgraph.py:38-39
     kw["n_nodes"], kw["n_edges"] = int(n_nodes), int(n_edges)
@@ -80,7 +84,7 @@ class _Space(SimpleNamespace):
 class VectorGraphEnv:
     """B independent envs of one id on one GPU.  One instance per process/GPU; no global state."""
 
-    def __init__(self, env_id, num_envs, n_nodes, n_edges, device="cuda", autoreset=True, obs_mode="pyg",
+    def __init__(self, env_id, num_envs, n_nodes, n_edges=-1, device="cuda", autoreset=True, obs_mode="pyg",
                  env_index_base=0, seed_stride=None, strict=False, _library=None, _views=None, node_id_base=0,
                  edge_row_stride=0, **kwargs):
         self.env_id = env_id
@@ -113,7 +117,8 @@ class VectorGraphEnv:
         self.F, self.Fe, self.A, self.W, self.E, self.obs_len = lay.F, lay.Fe, lay.A, lay.W, lay.E, int(lay.obs_len)
         B, n, E, W, A = self.num_envs, self.n, self.E, self.W, self.A
         AW = (A + 63) // 64
-        T = max(2, kw.get("n_dests", 0) + 1) if env_id == "SteinerTree-v0" else 2
+        edge_env = env_id in ("SteinerTree-v0", "MulticastRouting-v0")
+        T = max(2, kw.get("n_dests", 0) + 1) if edge_env else 2
         self.T = T
         dev = self.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
@@ -127,7 +132,7 @@ class VectorGraphEnv:
         t["sw64"] = z((B * E,), torch.float64) if kw.get("spatial", False) else None
         t["adj_bits"] = z((B * n, W), torch.int64)
         t["node_rec"] = z((B * n, 2), torch.int64) if W == 1 else None
-        t["rev_edge"] = z((B * E,), torch.int32) if env_id == "SteinerTree-v0" else None
+        t["rev_edge"] = z((B * E,), torch.int32) if edge_env else None
         t["head"] = z((B,), torch.int32)
         t["cur_rec"] = z((B, 2), torch.int64) if W == 1 else None
         t["terminals"] = z((B, T), torch.int32)
@@ -155,6 +160,7 @@ class VectorGraphEnv:
         t["work_list"] = z((B,), torch.int32)
         t["work_count"] = z((4,), torch.int32)
         t["feat_scratch"] = z((B, lay.feat_parts, n), torch.float64) if lay.feat_parts > 1 else None
+        t["node_aux"] = z((B, n), torch.int32) if env_id == "MulticastRouting-v0" and kw["parenting"] >= 3 else None
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 assert v.dtype == t[k].dtype and v.numel() >= (t[k].numel() if k != "edge_index" else 0), k
@@ -172,7 +178,7 @@ class VectorGraphEnv:
         self._actions_scratch = z((B,), torch.int64)
         self._flat = None
         self._was_reset = False
-        self.single_action_space = _Space(n=(self.m if env_id == "SteinerTree-v0" else n), mask_size=A)  # steiner_tree.py:43
+        self.single_action_space = _Space(n=(self.m if edge_env else n), mask_size=A)  # steiner_tree.py:43, multicast_routing.py:67
         self.single_observation_space = _Space(shape=(self.obs_len,), dtype=np.float32)
 
     # ------------------------------------------------------------------ plumbing

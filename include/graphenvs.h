@@ -31,7 +31,8 @@ enum {
   GE_STEINER_TREE = 2,        /* steiner_tree.py   SteinerTreeEnv    */
   GE_TSP = 3,                 /* tsp.py            TSPEnv            */
   GE_DENSEST_SUBGRAPH = 4,    /* densest_subgraph.py DensestSubgraphEnv */
-  GE_MAX_INDEPENDENT_SET = 5  /* max_independent_set.py MaxIndependentSet */
+  GE_MAX_INDEPENDENT_SET = 5, /* max_independent_set.py MaxIndependentSet */
+  GE_MULTICAST_ROUTING = 6    /* multicast_routing.py MulticastRoutingEnv */
 };
 
 enum {
@@ -52,7 +53,7 @@ typedef struct {
   int32_t n_edges;         /* undirected edge count m (E = 2m directed) */
   int32_t weighted;
   int32_t parenting;
-  int32_t n_dests;         /* SteinerTree */
+  int32_t n_dests;         /* SteinerTree, MulticastRouting */
   int32_t spatial;         /* TSP: node coordinates rand()*10, Euclidean float64 edge weights (tsp.py:79-86) */
   int32_t is_eval_env;
   int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset */
@@ -89,7 +90,7 @@ typedef struct {
   uint64_t *adj_bits;   /* [Nn, W]   adjacency bit rows                                     */
   uint64_t *node_rec;   /* [Nn, 2]   n <= 64 only: {bit row, weight codes of the 16 smallest neighbours as nibbles}:
                                      everything a step needs about a node in one 16-byte gather (else NULL) */
-  int32_t *rev_edge;    /* [Ne]      SteinerTree: local index of the reverse directed edge (else NULL) */
+  int32_t *rev_edge;    /* [Ne]      SteinerTree, MulticastRouting parenting 2: local index of the reverse directed edge (else NULL) */
   /* --- per-slot dynamic state */
   int32_t *head;        /* [B]  path head / TSP head                                        */
   uint64_t *cur_rec;    /* [B, 2] node_rec of the head, carried in the coalesced slot state (else NULL) */
@@ -122,6 +123,8 @@ typedef struct {
   int32_t *work_count;  /* [4]  [0] = entries in work_list                                             */
   double *feat_scratch; /* [B, parts, n] n > 64 only: betweenness partial sums when several workgroups share a slot
                                  (parts = ge_layout.feat_parts; NULL when parts == 1) */
+  int32_t *node_aux;    /* [B, n] MulticastRouting parenting >= 3: the one selectable edge into each node outside the tree
+                                 (argmin of distance-from-source, multicast_routing.py:164-186), -1 = none; else NULL */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;

@@ -70,6 +70,8 @@ CASES = {
     "mc_n64_m192_p4_d5": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), list(range(4))),
     "mc_n64_m192_p2_d8": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=8, parenting=2), list(range(3))),
     "mc_n200_m600_p4_d6": ("MulticastRouting-v0", dict(n_nodes=200, n_edges=600, n_dests=6), [0]),
+    "mc_n64_m192_p4_d40_eval": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=40, is_eval_env=True), list(range(3))),
+    "mc_n300_m900_p3_d4_eval": ("MulticastRouting-v0", dict(n_nodes=300, n_edges=900, n_dests=4, parenting=3, is_eval_env=True), [0]),
 }
 
 POLICIES = ("first", "rand")

@@ -49,6 +49,11 @@ CASES = [
     ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 64, 60),
     ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=60, parenting=0, is_eval_env=True), 64, 40),
     ("MaxIndependentSet-v0", dict(n_nodes=70, n_edges=200), 64, 150),
+    ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), 64, 80),
+    ("MulticastRouting-v0", dict(n_nodes=40, n_edges=100, n_dests=4, parenting=2), 48, 60),
+    ("MulticastRouting-v0", dict(n_nodes=30, n_edges=70, n_dests=6, parenting=3, is_eval_env=True), 48, 60),
+    ("MulticastRouting-v0", dict(n_nodes=20, n_edges=50, parenting=1), 32, 30),
+    ("MulticastRouting-v0", dict(n_nodes=150, n_edges=500, n_dests=8, is_eval_env=True), 16, 80),
 ]
 
 

@@ -12,6 +12,7 @@ CONFIGS = {
     "c4long": ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 16384, 700),
     "mis": ("MaxIndependentSet-v0", dict(n_nodes=64, n_edges=192), 65536, 130),
     "ds": ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 65536, 100),
+    "mc": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), 65536, 150),
 }
 for name in (sys.argv[1:] or ["c3", "c4"]):
     env_id, kw, B, K = CONFIGS[name]
