@@ -136,6 +136,7 @@ struct oge_env {
   int64_t edge_taken_cnt; int nodes_taken_cnt;
   uint8_t *alive; int n_alive; /* residual graph for parenting >= 2 */
   uint8_t *dtaken;             /* densest: python set nodes_taken */
+  uint8_t *inrange;            /* distribution center: in_range_dict[target i] as n flags per target */
   double n_choices;
   /* scratch */
   int *q, *dist, *stk, *pred_ptr, *pred;
@@ -144,7 +145,7 @@ struct oge_env {
   uint8_t *tmp8;
 };
 
-static int node_flag_count(int t) { return (t == OGE_TSP || t == OGE_MULTICAST_ROUTING) ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : 2); }
+static int node_flag_count(int t) { return (t == OGE_TSP || t == OGE_MULTICAST_ROUTING) ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : (t == OGE_DISTRIBUTION_CENTER ? 5 : 2)); }
 static int edge_actions(int t) { return t == OGE_STEINER_TREE || t == OGE_MULTICAST_ROUTING; }
 
 int oge_num_node_features(const oge_env *e) { return e->F; }
@@ -175,6 +176,7 @@ oge_env *oge_create(const oge_cfg *cfg) {
   e->mask = calloc(e->A + 1, 1); e->sf64 = calloc((size_t)n * 5, sizeof(double));
   e->terms = calloc(n + 1, sizeof(int));
   e->alive = calloc(n, 1); e->dtaken = calloc(n, 1);
+  e->inrange = calloc((size_t)(cfg->env_type == OGE_DISTRIBUTION_CENTER ? (cfg->n_dests > 0 ? cfg->n_dests : 1) : 1) * n, 1);
   e->q = calloc(n, sizeof(int)); e->dist = calloc(n, sizeof(int)); e->stk = calloc(n, sizeof(int));
   e->pred_ptr = calloc(n + 1, sizeof(int)); e->pred = calloc(e->E + 1, sizeof(int));
   e->sigma = calloc(n, sizeof(double)); e->delta = calloc(n, sizeof(double)); e->bc = calloc(n, sizeof(double));
@@ -194,7 +196,7 @@ void oge_destroy(oge_env *e) {
   free(e->sf64); free(e->terms); free(e->alive); free(e->dtaken); free(e->q); free(e->dist);
   free(e->stk); free(e->pred_ptr); free(e->pred); free(e->sigma); free(e->delta); free(e->bc);
   free(e->pr_x); free(e->pr_new); free(e->pr_data); free(e->pr_sinv); free(e->scol); free(e->sw);
-  free(e->tmp8); free(e);
+  free(e->tmp8); free(e->inrange); free(e);
 }
 
 /* ------------------------------------------------------------------ graph sampling */
@@ -497,6 +499,18 @@ static void compute_mask(oge_env *e) {
     case OGE_MAX_INDEPENDENT_SET: /* max_independent_set.py:92-100 */
       for (int v = 0; v < n; v++) e->mask[v] = (e->x[v * F + 1] == 0.0f);
       break;
+    case OGE_DISTRIBUTION_CENTER: { /* distribution_center.py:129-141 */
+      if (e->cfg.parenting == 2) {
+        memset(e->mask, 0, n);
+        for (int i = 0; i < e->n_targets; i++) {
+          int t = e->terms[i];
+          if (e->x[t * F + 3] != 0.f) continue; /* covered */
+          for (int v = 0; v < n; v++) if (e->inrange[(size_t)i * n + v]) e->mask[v] = 1;
+        }
+      } else memset(e->mask, 1, n);
+      for (int v = 0; v < n; v++) if (e->x[v * F + 1] == 1.f) e->mask[v] = 0;
+      break;
+    }
     case OGE_MULTICAST_ROUTING: { /* multicast_routing.py:155-188 */
       const int E = e->E, par = e->cfg.parenting;
       for (int p = 0; p < E; p++) e->mask[p] = !(e->ef[2 * p + 1] > 0.5f);
@@ -523,6 +537,13 @@ static void compute_mask(oge_env *e) {
       break;
     }
   }
+}
+
+/* distribution_center.py:25-26: nodes whose shortest 'delay' distance from `s` is <= cutoff ([nx] the cutoff only prunes:
+ * a node inside the range has its whole shortest-path prefix inside it) */
+static void nodes_in_range(oge_env *e, int s, double cutoff, uint8_t *out) {
+  dijkstra(e, s, -1);
+  for (int v = 0; v < e->n; v++) out[v] = e->sigma[v] <= cutoff;
 }
 
 /* ---- CPython 3.10 set of 2-tuples of small non-negative ints: iteration order (Objects/setobject.c, tupleobject.c).
@@ -744,6 +765,17 @@ int oge_reset(oge_env *e, int64_t seed) {
     e->x[0 * F + 3] = 0.f;
     e->head = 0; e->mc_failed = 1;
     for (int p = 0; p < e->E; p++) { e->ef[2 * p] = (float)e->w64[p]; e->ef[2 * p + 1] = 0.f; }
+  } else if (t == OGE_DISTRIBUTION_CENTER) { /* distribution_center.py:61-126 */
+    delay_matrix_weights(e);
+    build_directed(e);
+    double *cost = e->delta;
+    for (int v = 0; v < n; v++) cost[v] = (double)np_randint(e->np, 1, 4) / 1.0; /* :82, drawn for weighted and unweighted alike */
+    sample_terminals(e, e->cfg.n_dests); /* :87 */
+    e->n_targets = e->cfg.n_dests; e->heuristic = -1.0; e->head = -1; /* :91 */
+    for (int v = 0; v < n; v++) { e->x[v * F + 0] = (float)cost[v]; e->x[v * F + 4] = (float)e->cfg.max_distance; }
+    for (int i = 0; i < e->n_targets; i++) e->x[e->terms[i] * F + 2] = 1.f;
+    for (int p = 0; p < e->E; p++) e->ef[p] = (float)e->w64[p];
+    for (int i = 0; i < e->n_targets; i++) nodes_in_range(e, e->terms[i], e->cfg.max_distance, e->inrange + (size_t)i * n);
   } else { /* MIS: max_independent_set.py:53-60 */
     double *cost = e->sigma;
     for (int v = 0; v < n; v++) cost[v] = e->cfg.weighted ? (double)np_randint(e->np, 3, 10) / 10.0 : 1.0;
@@ -833,6 +865,25 @@ int oge_step(oge_env *e, int64_t action, double *reward, int32_t *done, int32_t 
       for (int u = 0; u < n; u++) if (e->x[u * F + 0] == 0.f && e->x[u * F + 1] == 1.f) missing++;
       if (missing == 0) { *done = 1; *solved = 1; }
       compute_mask(e);
+      *reward = (double)r;
+      return OGE_OK;
+    }
+    case OGE_DISTRIBUTION_CENTER: { /* distribution_center.py:144-178 */
+      if (action < 0 || action >= n || !e->mask[action]) return OGE_INVALID_ACTION;
+      int a = (int)action;
+      float r = -e->x[a * F + 0];
+      e->cost32 -= r;
+      e->x[a * F + 1] = 1.f;
+      nodes_in_range(e, a, e->cfg.max_distance, e->tmp8);
+      for (int v = 0; v < n; v++) {
+        if (!e->tmp8[v] || e->x[v * F + 3] == 1.f) continue;
+        e->x[v * F + 3] = 1.f;
+        if (e->x[v * F + 2] == 1.f) r += 1;
+      }
+      compute_mask(e);
+      int left = 0;
+      for (int v = 0; v < n; v++) if (e->x[v * F + 2] == 1.f && e->x[v * F + 3] == 0.f) left++;
+      if (left == 0) { *done = 1; *solved = 1; }
       *reward = (double)r;
       return OGE_OK;
     }
@@ -929,7 +980,7 @@ void oge_get_features64(const oge_env *e, double *sf) { memcpy(sf, e->sf64, (siz
 double oge_solution_cost(const oge_env *e) {
   int t = e->cfg.env_type;
   if (t == OGE_MULTICAST_ROUTING) return e->mc_failed ? -1.0 : (double)e->cost32; /* multicast_routing.py:203,262 */
-  return (t == OGE_STEINER_TREE || t == OGE_MAX_INDEPENDENT_SET) ? (double)e->cost32 : e->cost64;
+  return (t == OGE_STEINER_TREE || t == OGE_MAX_INDEPENDENT_SET || t == OGE_DISTRIBUTION_CENTER) ? (double)e->cost32 : e->cost64;
 }
 double oge_heuristic_solution(const oge_env *e) { return e->heuristic; }
 int oge_head(const oge_env *e) { return e->head; }

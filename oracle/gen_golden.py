@@ -71,6 +71,15 @@ CASES = {
     "mc_n64_m192_p2_d8": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=8, parenting=2), list(range(3))),
     "mc_n200_m600_p4_d6": ("MulticastRouting-v0", dict(n_nodes=200, n_edges=600, n_dests=6), [0]),
     "mc_n64_m192_p4_d40_eval": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=40, is_eval_env=True), list(range(3))),
+    # DistributionCenter (distribution_center.py)
+    "dc_n10_m20_p2": ("DistributionCenter-v0", dict(n_nodes=10, n_edges=20), list(range(10))),
+    "dc_n10_m20_p1": ("DistributionCenter-v0", dict(n_nodes=10, n_edges=20, parenting=1), list(range(6))),
+    "dc_n12_m25_p2_unweighted_t4": ("DistributionCenter-v0", dict(n_nodes=12, n_edges=25, weighted=False, target_count=4), list(range(6))),
+    "dc_n20_m40_p2_dist1p5_eval": ("DistributionCenter-v0", dict(n_nodes=20, n_edges=40, max_distance=1.5, is_eval_env=True), list(range(6))),
+    "dc_n64_m192_p2": ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), list(range(6))),
+    "dc_n64_m192_p2_dist0p7": ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192, max_distance=0.7, target_count=20), list(range(4))),
+    "dc_n200_m600_p2": ("DistributionCenter-v0", dict(n_nodes=200, n_edges=600), [0, 1]),
+    "dc_n300_m900_p1_dist2": ("DistributionCenter-v0", dict(n_nodes=300, n_edges=900, parenting=1, max_distance=2), [0]),
     "mc_n300_m900_p3_d4_eval": ("MulticastRouting-v0", dict(n_nodes=300, n_edges=900, n_dests=4, parenting=3, is_eval_env=True), [0]),
 }
 
@@ -97,6 +106,8 @@ def terminals_of(env, env_id):
         return [0]
     if env_id == "MulticastRouting-v0":
         return [int(env.src)] + [int(d) for d in env.dests]
+    if env_id == "DistributionCenter-v0":
+        return [int(t) for t in env.in_range_dict]  # targets, in the order they were drawn
     return []
 
 

@@ -20,6 +20,7 @@ ENV_TYPES = {
     "DensestSubgraph-v0": 4,
     "MaxIndependentSet-v0": 5,
     "MulticastRouting-v0": 6,
+    "DistributionCenter-v0": 7,
 }
 
 
@@ -27,7 +28,7 @@ class OgeCfg(C.Structure):
     _fields_ = [
         ("env_type", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
         ("weighted", C.c_int32), ("parenting", C.c_int32), ("n_dests", C.c_int32),
-        ("spatial", C.c_int32), ("is_eval_env", C.c_int32), ("n_choices", C.c_double),
+        ("spatial", C.c_int32), ("is_eval_env", C.c_int32), ("n_choices", C.c_double), ("max_distance", C.c_double),
     ]
 
 
@@ -86,7 +87,7 @@ def lib():
 
 
 def make_cfg(env_id, n_nodes, n_edges=-1, weighted=None, parenting=None, n_dests=3, spatial=False,
-             is_eval_env=False, n_choices=-1, **_ignored) -> OgeCfg:
+             is_eval_env=False, n_choices=-1, max_distance=1, target_count=-1, **_ignored) -> OgeCfg:
     t = ENV_TYPES[env_id]
     if parenting is None:
         parenting = 4 if t == 6 else -1  # multicast_routing.py:31
@@ -95,8 +96,11 @@ def make_cfg(env_id, n_nodes, n_edges=-1, weighted=None, parenting=None, n_dests
         n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # multicast_routing.py:53-54
     if weighted is None:
         weighted = (t != 4)  # DensestSubgraph defaults to weighted=False (densest_subgraph.py:25)
+    if t == 7:  # distribution_center.py:29,42-45
+        parenting = 2 if parenting == -1 else parenting
+        n_dests = n_nodes // 5 if target_count == -1 else target_count
     return OgeCfg(t, n_nodes, n_edges, int(bool(weighted)), int(parenting), int(n_dests),
-                  int(bool(spatial)), int(bool(is_eval_env)), float(n_choices))
+                  int(bool(spatial)), int(bool(is_eval_env)), float(n_choices), float(max_distance))
 
 
 class OracleEnv:
