@@ -23,6 +23,7 @@ ENV_TYPES = {
     "DensestSubgraph-v0": 4,
     "MaxIndependentSet-v0": 5,
     "MulticastRouting-v0": 6,
+    "DistributionCenter-v0": 7,
 }
 
 
@@ -32,7 +33,7 @@ class GeConfig(C.Structure):
         ("weighted", C.c_int32), ("parenting", C.c_int32), ("n_dests", C.c_int32), ("spatial", C.c_int32),
         ("is_eval_env", C.c_int32), ("autoreset", C.c_int32), ("n_choices", C.c_double),
         ("env_index_base", C.c_int64), ("seed_stride", C.c_int64), ("node_id_base", C.c_int64),
-        ("edge_row_stride", C.c_int64),
+        ("edge_row_stride", C.c_int64), ("max_distance", C.c_double),
     ]
 
 
@@ -49,7 +50,7 @@ BUFFER_FIELDS = [
     "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic", "mt_state",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
     "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
-    "node_aux",
+    "node_aux", "range_bits", "cover_bits",
 ]
 
 

@@ -48,7 +48,9 @@ struct GeParams {
   int32_t spatial;   // TSP with coordinates and float64 Euclidean weights (sw64 slab)
   int32_t feat_parts;   // n > 64: workgroups sharing one slot's BFS sources in the feature kernel
   int32_t np_early;  // the numpy wave can produce every weight code without the topology (dense delay matrix fits LDS)
+  int32_t cost_off;  // DistributionCenter: byte offset of the node-cost list inside the wm scratch
   double n_choices;
+  double max_distance;  // DistributionCenter coverage radius
   int64_t env_index_base, seed_stride, node_id_base, edge_row_stride;
   ge_buffers buf;
   GeLds lds;
@@ -65,6 +67,8 @@ static inline void ge_make_lds(GeParams &P) {
   L.mt2 = take(GE_MT_N * 4);
   { int nb = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 16; if (P.m > nb) nb = P.m; if (P.n > nb) nb = P.n;
     if (P.spatial && 32 * P.n > nb) nb = 32 * P.n;  // raw draws u32[4n] + coordinates f64[2n]
+    P.cost_off = 0;
+    if (P.env_type == GE_DISTRIBUTION_CENTER) { P.cost_off = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 0; if (P.cost_off + P.n > nb) nb = P.cost_off + P.n; }
     L.wm = take(nb); }
   L.abits = take(P.n * P.W * 8);
   L.elist = take((P.m > 0 ? P.m : 1) * 4);

@@ -238,7 +238,8 @@ __device__ unsigned long long ge_stamp_buf[32];
 
 // masked-rejection draws of randint(3, 10) ([np] buffered_bounded_masked_uint32), 64 per round: draw k of the
 // accepted sequence gets code 3 + value.  sink 0: nibble matrix wm[k] (k = i*n + j of the delay matrix);
-// sink 1: byte list wm[k]; sink 2: delay[i, j] lands by rank in wsort (needs the topology).  One wave.
+// sink 1: byte list wm[k]; sink 2: delay[i, j] lands by rank in wsort (needs the topology); sink 3: randint(1, 4) node costs
+// (mask 3, reject > 2; distribution_center.py:82) as a byte list at wm + cost_off.  One wave.
 GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int total, int lane, int sink) {
   const int n = P.n, W = P.W;
   int base = 0;
@@ -246,14 +247,16 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
     {
       const int p = nppos + lane; const bool valid = p < GE_MT_N;
-      const uint32_t val = valid ? (ge_temper(mt[p]) & 7u) : 8u;
-      const bool acc = valid && val <= 6u;
+      const uint32_t bm = (sink == 3) ? 3u : 7u;
+      const uint32_t val = valid ? (ge_temper(mt[p]) & bm) : 8u;
+      const bool acc = valid && val < bm;
       const uint64_t bal = ge_ballot(acc);
       const int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
       const int idx = base + rank;
       if (acc && idx < total) {
-        const uint32_t code = 3u + val;
-        if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
+        const uint32_t code = (sink == 3 ? 1u : 3u) + val;
+        if (sink == 3) ((uint8_t *)c.wm)[P.cost_off + idx] = (uint8_t)code;
+        else if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
         else if (sink == 1) ((uint8_t *)c.wm)[idx] = (uint8_t)code;
         else {
           const int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
@@ -334,7 +337,7 @@ GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, in
 
 // [nx] dijkstra from `src` to every node: least fixpoint of d[u] = min_v fl(d[v] + w(v,u)) (float addition is monotone, so
 // the distances do not depend on the relaxation order); Jacobi sweeps in LDS.  Distances are left in c.sigma.
-GE_DEV void ge_dijkstra_wave(const GeRctx &c, int n, int src, int lane) {
+GE_DEV void ge_dijkstra_wave(const GeRctx &c, int n, int src, int lane, double cutoff = __builtin_inf()) {
   for (int v = lane; v < n; v += GE_WAVE) c.sigma[v] = (v == src) ? 0.0 : __builtin_inf();
   ge_wave_sync();
   for (int it = 0; it < n; it++) {
@@ -345,7 +348,7 @@ GE_DEV void ge_dijkstra_wave(const GeRctx &c, int n, int src, int lane) {
         double best = c.sigma[v];
         for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
           double d = c.sigma[c.colw[k] >> 4] + ge_wlut(c.colw[k] & 15);
-          if (d < best) { best = d; ch = true; }
+          if (d < best && d <= cutoff) { best = d; ch = true; }  // beyond the cutoff nothing is needed: a node inside it has its whole shortest-path prefix inside
         }
         c.delta[v] = best;
       }
@@ -500,7 +503,7 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
   GE_STAMP(21);
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
-  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
+  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER);
   if (P.spatial) {  // tsp.py:81-83: x, y = np.random.rand() * 10 per node; rand() = two 32-bit draws, no rejection
     uint32_t *raw = c.wm; double *xy = (double *)(c.wm + 4 * n);
     for (int p0 = 0; p0 < 4 * n; p0 += GE_WAVE) {
@@ -525,6 +528,7 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
     } else ge_np_draws(P, c, c.mt2, nppos, t == GE_TSP ? P.m : n, lane, 1);
   }
   GE_STAMP(22);
+  if (t == GE_DISTRIBUTION_CENTER) ge_np_draws(P, c, c.mt2, nppos, n, lane, 3);  // node costs, weighted or not
   if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
   else if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane, n);
   GE_STAMP(23);
@@ -722,8 +726,9 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   if (mode != GE_RESET_INJECT) {
     for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
     ge_wave_sync();
-    const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
-    if (P.weighted && path_like && P.np_early) {  // delay[u, v], u < v, from the nibble matrix the numpy wave filled
+    const bool path_like = path_like_t;
+    const bool matrix_w = path_like_t || t == GE_DISTRIBUTION_CENTER;  // delay[u, v] of an n x n randint matrix
+    if (P.weighted && matrix_w && P.np_early) {  // delay[u, v], u < v, from the nibble matrix the numpy wave filled
       for (int idx = lane; idx < E; idx += GE_WAVE) {
         int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
         int a = u < v ? u : v, b = u < v ? v : u, cell = a * n + b;
@@ -752,9 +757,10 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       }
     } else if (t == GE_MAX_INDEPENDENT_SET) {
       for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = P.weighted ? (int)((const uint8_t *)c.wm)[v] : 10;
-    } else if (P.weighted && path_like) {  // n too large for the dense matrix: draw now, codes land by rank
+    } else if (P.weighted && matrix_w) {  // n too large for the dense matrix: draw now, codes land by rank
       int nppos = GE_MT_N;
       ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 2);
+      if (t == GE_DISTRIBUTION_CENTER) ge_np_draws(P, c, c.mt2, nppos, n, lane, 3);
       if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
       else ge_np_terminals(P, c, c.mt2, nppos, lane, n);
     }
@@ -772,10 +778,10 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)(c.colw[idx] & 15);
     }
     ge_wave_sync();
-    if (path_like_t) {
+    if (path_like_t || t == GE_DISTRIBUTION_CENTER) {
       for (int k = lane; k < T; k += GE_WAVE) c.perm[k] = inj.terminals[(int64_t)env * T + k];
       ge_wave_sync();
-      src = c.perm[0]; dest = c.perm[1];
+      if (path_like_t) { src = c.perm[0]; dest = c.perm[1]; }
     }
   }
   if (t == GE_TSP) { src = 0; dest = -1; }
@@ -819,6 +825,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     } else if (t == GE_DENSEST_SUBGRAPH) heuristic = -1.0;             // densest_subgraph.py:85-88
     else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : kNaN;  // greedy MIS not built
     else if (t == GE_MULTICAST_ROUTING) heuristic = 0.0;                 // computed below, after the delay bound
+    else if (t == GE_DISTRIBUTION_CENTER) heuristic = -1.0;              // distribution_center.py:91
     else heuristic = kNaN;                                              // Kou / Christofides not built
   }
 
@@ -839,6 +846,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (P.is_eval) heuristic = ge_multicast_baseline(P, c, env, lane);
   }
 
+  if (t == GE_DISTRIBUTION_CENTER) heuristic = -1.0;  // distribution_center.py:91, eval or not
   GE_STAMP(9);
   // ------------------------------------------------------------------ write the slot to HBM
   const ge_buffers &G = P.buf;
@@ -848,6 +856,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     uint64_t tb = 0;
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) { if ((dest >> 6) == lane) tb = 1ull << (dest & 63); }
     else if (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING) for (int k = 1; k <= P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
+    else if (t == GE_DISTRIBUTION_CENTER) for (int k = 0; k < P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
     tbits[lane] = tb;
   }
   ge_wave_sync();
@@ -864,6 +873,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       else if (t == GE_MAX_INDEPENDENT_SET) val = (col == 0) ? (float)ge_wlut(c.fill[v]) : 0.f;
       else if (t == GE_MULTICAST_ROUTING)  // HAS_MSG, IS_TARGET, MAX_DISTANCE, DISTANCE_FROM_SOURCE (multicast_routing.py:124-129)
         val = (col == 0) ? (v == src ? 1.f : 0.f) : (col == 1) ? (is_t ? 1.f : 0.f) : (col == 2) ? (float)max_distance : (v == src ? 0.f : -1.f);
+      else if (t == GE_DISTRIBUTION_CENTER)  // WEIGHT, IS_TAKEN, IS_TARGET, IS_COVERED, MAX_DISTANCE (distribution_center.py:99-102)
+        val = (col == 0) ? (float)((const uint8_t *)c.wm)[P.cost_off + v] : (col == 2) ? (is_t ? 1.f : 0.f) : (col == 4) ? (float)P.max_distance : 0.f;
       G.x[(nbase + v) * F + col] = val;
     }
   }
@@ -886,7 +897,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       uint64_t codes = 0; int d = c.rowptr[v + 1] - c.rowptr[v]; if (d > 16) d = 16;
       for (int k = 0; k < d; k++) codes |= (uint64_t)(c.wsort[c.rowptr[v] + k] & 15) << (4 * k);
       G.node_rec[(nbase + v) * 2] = c.abits[v]; G.node_rec[(nbase + v) * 2 + 1] = codes;
-      const int h0 = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 0 : src;
+      const int h0 = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? 0 : src;
       if (v == h0) { G.cur_rec[(int64_t)env * 2] = c.abits[v]; G.cur_rec[(int64_t)env * 2 + 1] = codes; }
     }
   }
@@ -920,6 +931,23 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       ge_wave_sync();
     }
   }
+  if (t == GE_DISTRIBUTION_CENTER) {
+    // distribution_center.py:25-26,117-118: nodes within max_distance of every node, each from that node as the source
+    // (float sums depend on the direction); the first mask is the union over the targets
+    uint64_t *acc = c.bits + 5 * W;
+    if (lane < W) acc[lane] = 0ull;
+    ge_wave_sync();
+    for (int s = 0; s < n; s++) {
+      ge_dijkstra_wave(c, n, s, lane, P.max_distance);
+      const bool s_is_target = (tbits[s >> 6] >> (s & 63)) & 1ull;
+      for (int w0 = 0; w0 < W; w0++) {
+        const int v = w0 * GE_WAVE + lane;
+        const uint64_t word = ge_ballot(v < n && c.sigma[v] <= P.max_distance);
+        if (lane == 0) { G.range_bits[(nbase + s) * W + w0] = word; if (s_is_target) acc[w0] |= word; }
+      }
+      ge_wave_sync();
+    }
+  }
   for (int w = lane; w < AW; w += GE_WAVE) {
     uint64_t mb;
     int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;
@@ -931,7 +959,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       int a = c.rowptr[src], b = c.rowptr[src + 1]; mb = 0;
       int l2 = a > lo ? a : lo, h2 = b < hi ? b : hi;
       if (h2 > l2) mb = ((h2 - l2 == 64) ? ~0ull : ((1ull << (h2 - l2)) - 1ull)) << (l2 - lo);
-    } else mb = full;  // LP parenting 0, Densest first step, MIS
+    } else if (t == GE_DISTRIBUTION_CENTER && P.parenting == 2) mb = (c.bits + 5 * W)[w];
+    else mb = full;  // LP parenting 0, Densest first step, MIS, DistributionCenter parenting 1
     G.mask_bits[(int64_t)env * AW + w] = mb;
     ((uint64_t *)c.sigma)[w] = mb;  // staged for the byte expansion below (sigma is free now)
   }
@@ -942,15 +971,16 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     if (node_started && (src >> 6) == w) nb = 1ull << (src & 63);
     G.node_bits[(int64_t)env * W + w] = nb;
     G.target_bits[(int64_t)env * W + w] = tbits[w];
+    if (G.cover_bits) G.cover_bits[(int64_t)env * W + w] = 0ull;
   }
   if (G.node_aux) {  // multicast parenting >= 3: the selectable edge into every node
     for (int v = lane; v < n; v += GE_WAVE) G.node_aux[nbase + v] = -1;
     ge_wave_sync();
     for (int k = c.rowptr[src] + lane; k < c.rowptr[src + 1]; k += GE_WAVE) G.node_aux[nbase + (c.colw[k] >> 4)] = k;
   }
-  for (int k = lane; k < T; k += GE_WAVE) G.terminals[(int64_t)env * T + k] = (t == GE_TSP) ? 0 : ((t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : c.perm[k]);
+  for (int k = lane; k < T; k += GE_WAVE) G.terminals[(int64_t)env * T + k] = (t == GE_TSP) ? 0 : ((t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : ((t == GE_DISTRIBUTION_CENTER && k >= P.n_dests) ? -1 : c.perm[k]));
   if (lane == 0) {
-    G.head[env] = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : src;
+    G.head[env] = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? -1 : src;
     G.cost[env] = 0.0; G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
     G.status[env] = 0; G.heuristic[env] = heuristic;
     if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }

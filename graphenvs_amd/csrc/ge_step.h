@@ -276,6 +276,36 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
           else if (!any) { done = 1; solved = 0; reward = fail; }
           break;
         }
+        case GE_DISTRIBUTION_CENTER: {  // distribution_center.py:144-178
+          if (!mbit) { invalid = 1; break; }
+          acted = true;
+          float r = -G.x[(nbase + a) * F + 0];
+          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;  // numpy float32 accumulator
+          G.x[(nbase + a) * F + 1] = 1.f;
+          uint64_t *taken = G.node_bits + (int64_t)i * W, *cov = G.cover_bits + (int64_t)i * W;
+          const uint64_t *tg = G.target_bits + (int64_t)i * W, *Ra = G.range_bits + (nbase + a) * W;
+          taken[a >> 6] |= 1ull << (a & 63);
+          uint64_t left = 0;
+          for (int w = 0; w < W; w++) {  // cover what is in range of the new centre; +1 per target covered for the first time
+            const uint64_t old = cov[w], fresh = Ra[w] & ~old;
+            cov[w] = old | Ra[w];
+            for (uint64_t f = fresh; f; f &= f - 1) G.x[(nbase + w * 64 + ge_ctz64(f)) * F + 3] = 1.f;
+            r += (float)ge_popc64(fresh & tg[w]);
+            left |= tg[w] & ~(old | Ra[w]);
+            stage[tid * W + w] = (P.parenting == 2) ? 0ull : ge_full_word(A, w);
+          }
+          if (P.parenting == 2)  // union of the ranges of the targets still uncovered (distribution_center.py:133-135)
+            for (int w0 = 0; w0 < W; w0++)
+              for (uint64_t tl = tg[w0] & ~cov[w0]; tl; tl &= tl - 1) {
+                const uint64_t *Rt = G.range_bits + (nbase + w0 * 64 + ge_ctz64(tl)) * W;
+                for (int w = 0; w < W; w++) stage[tid * W + w] |= Rt[w];
+              }
+          for (int w = 0; w < W; w++) stage[tid * W + w] &= ~taken[w];
+          wrote_mask = true;
+          reward = (double)r;
+          if (!left) { done = 1; solved = 1; }
+          break;
+        }
         case GE_DENSEST_SUBGRAPH: {
           bool taken_a = in_range && ((G.node_bits[(int64_t)i * W + (a >> 6)] >> (a & 63)) & 1ull);
           if (!mbit || taken_a) { invalid = 1; break; }

@@ -8,7 +8,8 @@ import torch
 
 from .vector_env import VectorGraphEnv
 
-_F32_REWARD = ("SteinerTree-v0", "MaxIndependentSet-v0", "MulticastRouting-v0")  # steiner_tree.py:137, max_independent_set.py:109, multicast_routing.py:200
+# steiner_tree.py:137, max_independent_set.py:109, multicast_routing.py:200, distribution_center.py:150
+_F32_REWARD = ("SteinerTree-v0", "MaxIndependentSet-v0", "MulticastRouting-v0", "DistributionCenter-v0")
 
 
 class GraphEnv:

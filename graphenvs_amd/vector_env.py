@@ -26,6 +26,7 @@ _DEFAULTS = {
     "DensestSubgraph-v0": dict(weighted=False, n_choices=-1, return_graph_obs=False, is_eval_env=False, parenting=-1),
     "MaxIndependentSet-v0": dict(weighted=True, return_graph_obs=False, is_eval_env=False),
     "MulticastRouting-v0": dict(n_dests=3, weighted=True, max_distance=-1, parenting=4, is_eval_env=False),
+    "DistributionCenter-v0": dict(weighted=True, max_distance=1, target_count=-1, return_graph_obs=False, is_eval_env=False, parenting=2),
 }
 
 
@@ -51,6 +52,10 @@ def normalize_kwargs(env_id, n_nodes, n_edges=-1, **kwargs):
     if env_id == "DensestSubgraph-v0":
         assert kw["parenting"] in [0, 1], "Parenting must be 0 or 1"  # densest_subgraph.py:28
         assert kw["weighted"] == False, "Weighted graphs not supported for this env"  # noqa: E712
+    if env_id == "DistributionCenter-v0":
+        assert kw["parenting"] in [1, 2]  # distribution_center.py:32
+        if kw["target_count"] == -1:
+            kw["target_count"] = n_nodes // 5  # distribution_center.py:42-45
     if env_id == "MulticastRouting-v0" and kw["parenting"] not in [1, 2, 3, 4]:
         raise ValueError("Invalid parenting type")  # multicast_routing.py:34-35
     if env_id in ("LongestPath-v0", "DensestSubgraph-v0", "MulticastRouting-v0") and n_edges == -1:
@@ -108,9 +113,10 @@ class VectorGraphEnv:
         self.env_index_base = int(env_index_base)
         self.cfg = _lib.GeConfig(
             _lib.ENV_TYPES[env_id], self.num_envs, self.n, self.m, int(bool(kw.get("weighted", False))),
-            int(kw.get("parenting", -1)), int(kw.get("n_dests", 0)), int(bool(kw.get("spatial", False))),
+            int(kw.get("parenting", -1)), int(kw.get("n_dests", kw.get("target_count", 0))), int(bool(kw.get("spatial", False))),
             int(bool(kw.get("is_eval_env", False))), int(self.autoreset), float(kw.get("n_choices", -1)),
-            self.env_index_base, self.seed_stride, int(node_id_base), int(edge_row_stride))
+            self.env_index_base, self.seed_stride, int(node_id_base), int(edge_row_stride),
+            float(kw["max_distance"]) if env_id == "DistributionCenter-v0" else 0.0)
         lay = _lib.GeLayout()
         _lib.check(self._L, self._L.ge_get_layout(C.byref(self.cfg), C.byref(lay)), "ge_get_layout")
         self.layout = lay
@@ -118,7 +124,7 @@ class VectorGraphEnv:
         B, n, E, W, A = self.num_envs, self.n, self.E, self.W, self.A
         AW = (A + 63) // 64
         edge_env = env_id in ("SteinerTree-v0", "MulticastRouting-v0")
-        T = max(2, kw.get("n_dests", 0) + 1) if edge_env else 2
+        T = max(2, kw.get("n_dests", 0) + 1) if edge_env else max(2, kw.get("target_count", 0))
         self.T = T
         dev = self.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
@@ -161,6 +167,9 @@ class VectorGraphEnv:
         t["work_count"] = z((4,), torch.int32)
         t["feat_scratch"] = z((B, lay.feat_parts, n), torch.float64) if lay.feat_parts > 1 else None
         t["node_aux"] = z((B, n), torch.int32) if env_id == "MulticastRouting-v0" and kw["parenting"] >= 3 else None
+        dc = env_id == "DistributionCenter-v0"
+        t["range_bits"] = z((B * n, W), torch.int64) if dc else None
+        t["cover_bits"] = z((B, W), torch.int64) if dc else None
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 assert v.dtype == t[k].dtype and v.numel() >= (t[k].numel() if k != "edge_index" else 0), k

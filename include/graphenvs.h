@@ -32,7 +32,8 @@ enum {
   GE_TSP = 3,                 /* tsp.py            TSPEnv            */
   GE_DENSEST_SUBGRAPH = 4,    /* densest_subgraph.py DensestSubgraphEnv */
   GE_MAX_INDEPENDENT_SET = 5, /* max_independent_set.py MaxIndependentSet */
-  GE_MULTICAST_ROUTING = 6    /* multicast_routing.py MulticastRoutingEnv */
+  GE_MULTICAST_ROUTING = 6,   /* multicast_routing.py MulticastRoutingEnv */
+  GE_DISTRIBUTION_CENTER = 7  /* distribution_center.py DistributionCenterEnv */
 };
 
 enum {
@@ -53,7 +54,7 @@ typedef struct {
   int32_t n_edges;         /* undirected edge count m (E = 2m directed) */
   int32_t weighted;
   int32_t parenting;
-  int32_t n_dests;         /* SteinerTree, MulticastRouting */
+  int32_t n_dests;         /* SteinerTree, MulticastRouting; DistributionCenter: target_count */
   int32_t spatial;         /* TSP: node coordinates rand()*10, Euclidean float64 edge weights (tsp.py:79-86) */
   int32_t is_eval_env;
   int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset */
@@ -63,6 +64,7 @@ typedef struct {
   int64_t node_id_base;    /* added to every node id written to edge_index: lets several engines of different
                               geometry share one PyG slab (ragged batch: variable-size CSR packing) */
   int64_t edge_row_stride; /* elements between the two rows of edge_index; 0 = num_envs * 2 * n_edges */
+  double max_distance;     /* DistributionCenter: coverage radius (distribution_center.py:29, default 1) */
 } ge_config;
 
 /* Sizes (in elements) of every caller-allocated device buffer for a config. */
@@ -125,6 +127,9 @@ typedef struct {
                                  (parts = ge_layout.feat_parts; NULL when parts == 1) */
   int32_t *node_aux;    /* [B, n] MulticastRouting parenting >= 3: the one selectable edge into each node outside the tree
                                  (argmin of distance-from-source, multicast_routing.py:164-186), -1 = none; else NULL */
+  uint64_t *range_bits; /* [B, n, W] DistributionCenter: nodes within max_distance of each node, from that node as the
+                                 Dijkstra source (distribution_center.py:25-26); else NULL */
+  uint64_t *cover_bits; /* [B, W] DistributionCenter: covered nodes; else NULL */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;

@@ -20,7 +20,8 @@ FAST = ["sp_n10_m20_eval", "sp_n5_m7", "sp_n33_m70", "sp_n64_m192_eval", "lp_n10
         "ds_n10_m20_p0_eval", "ds_n100_m300_p1", "sp_n10_m20_unweighted", "st_n10_m20_d3_unweighted",
         "lp_n10_m20_p2", "lp_n64_m192_p2", "tsp_n10_m20_p2", "tsp_n12_m30_p2_spatial",
         "mc_n10_m20_p4", "mc_n10_m20_p3_d2", "mc_n10_m20_p2", "mc_n10_m20_p1", "mc_n10_m20_p4_eval",
-        "mc_n12_auto_edges_p4_unweighted", "mc_n64_m192_p4_d40_eval"]
+        "mc_n12_auto_edges_p4_unweighted", "mc_n64_m192_p4_d40_eval",
+        "dc_n10_m20_p2", "dc_n10_m20_p1", "dc_n12_m25_p2_unweighted_t4", "dc_n20_m40_p2_dist1p5_eval", "dc_n64_m192_p2_dist0p7"]
 
 
 @pytest.fixture(scope="module")

@@ -54,6 +54,9 @@ CASES = [
     ("MulticastRouting-v0", dict(n_nodes=30, n_edges=70, n_dests=6, parenting=3, is_eval_env=True), 48, 60),
     ("MulticastRouting-v0", dict(n_nodes=20, n_edges=50, parenting=1), 32, 30),
     ("MulticastRouting-v0", dict(n_nodes=150, n_edges=500, n_dests=8, is_eval_env=True), 16, 80),
+    ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), 64, 40),
+    ("DistributionCenter-v0", dict(n_nodes=30, n_edges=70, parenting=1, max_distance=0.8, target_count=10), 48, 40),
+    ("DistributionCenter-v0", dict(n_nodes=100, n_edges=260, weighted=False, is_eval_env=True), 16, 60),
 ]
 
 
