@@ -137,6 +137,9 @@ struct oge_env {
   uint8_t *alive; int n_alive; /* residual graph for parenting >= 2 */
   uint8_t *dtaken;             /* densest: python set nodes_taken */
   uint8_t *inrange;            /* distribution center: in_range_dict[target i] as n flags per target */
+  double *fw;                  /* perishable delivery: floyd_warshall matrix */
+  int pickups[5], dropoffs[5]; /* perishable delivery */
+  double delivery_time, cost_prev;
   double n_choices;
   /* scratch */
   int *q, *dist, *stk, *pred_ptr, *pred;
@@ -145,7 +148,7 @@ struct oge_env {
   uint8_t *tmp8;
 };
 
-static int node_flag_count(int t) { return (t == OGE_TSP || t == OGE_MULTICAST_ROUTING) ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : (t == OGE_DISTRIBUTION_CENTER ? 5 : 2)); }
+static int node_flag_count(int t) { return (t == OGE_TSP || t == OGE_MULTICAST_ROUTING) ? 4 : (t == OGE_DENSEST_SUBGRAPH ? 1 : (t == OGE_DISTRIBUTION_CENTER ? 5 : (t == OGE_PERISHABLE_DELIVERY ? 16 : 2))); }
 static int edge_actions(int t) { return t == OGE_STEINER_TREE || t == OGE_MULTICAST_ROUTING; }
 
 int oge_num_node_features(const oge_env *e) { return e->F; }
@@ -176,6 +179,7 @@ oge_env *oge_create(const oge_cfg *cfg) {
   e->mask = calloc(e->A + 1, 1); e->sf64 = calloc((size_t)n * 5, sizeof(double));
   e->terms = calloc(n + 1, sizeof(int));
   e->alive = calloc(n, 1); e->dtaken = calloc(n, 1);
+  e->fw = calloc(cfg->env_type == OGE_PERISHABLE_DELIVERY ? nn : 1, sizeof(double));
   e->inrange = calloc((size_t)(cfg->env_type == OGE_DISTRIBUTION_CENTER ? (cfg->n_dests > 0 ? cfg->n_dests : 1) : 1) * n, 1);
   e->q = calloc(n, sizeof(int)); e->dist = calloc(n, sizeof(int)); e->stk = calloc(n, sizeof(int));
   e->pred_ptr = calloc(n + 1, sizeof(int)); e->pred = calloc(e->E + 1, sizeof(int));
@@ -196,7 +200,7 @@ void oge_destroy(oge_env *e) {
   free(e->sf64); free(e->terms); free(e->alive); free(e->dtaken); free(e->q); free(e->dist);
   free(e->stk); free(e->pred_ptr); free(e->pred); free(e->sigma); free(e->delta); free(e->bc);
   free(e->pr_x); free(e->pr_new); free(e->pr_data); free(e->pr_sinv); free(e->scol); free(e->sw);
-  free(e->tmp8); free(e->inrange); free(e);
+  free(e->tmp8); free(e->inrange); free(e->fw); free(e);
 }
 
 /* ------------------------------------------------------------------ graph sampling */
@@ -511,6 +515,12 @@ static void compute_mask(oge_env *e) {
       for (int v = 0; v < n; v++) if (e->x[v * F + 1] == 1.f) e->mask[v] = 0;
       break;
     }
+    case OGE_PERISHABLE_DELIVERY: { /* perishable_product_delivery.py:176-196 (parenting 1) */
+      memset(e->mask, 0, n);
+      for (int i = 0; i < e->cfg.n_dests; i++) if (e->x[e->head * F + 1 + i] == 1.f) e->mask[e->head] = 1;
+      for (int k = e->row_ptr[e->head]; k < e->row_ptr[e->head + 1]; k++) e->mask[e->col[k]] = 1;
+      break;
+    }
     case OGE_MULTICAST_ROUTING: { /* multicast_routing.py:155-188 */
       const int E = e->E, par = e->cfg.parenting;
       for (int p = 0; p < E; p++) e->mask[p] = !(e->ef[2 * p + 1] > 0.5f);
@@ -537,6 +547,39 @@ static void compute_mask(oge_env *e) {
       break;
     }
   }
+}
+
+/* perishable_product_delivery.py:75-111: one attempt at placing the products on a connected graph.  Returns 0 when
+ * a pickup has no drop-off in range (the reference then samples a new graph; pickups / dropoffs keep what was set). */
+static int in_list5(const int *a, int k, int v) { for (int i = 0; i < k; i++) if (a[i] == v) return 1; return 0; }
+static int perishable_place_products(oge_env *e) {
+  int n = e->n, np_ = e->cfg.n_dests;
+  e->delivery_time = np_rand(e->np) * (e->cfg.dt_max - e->cfg.dt_min) + e->cfg.dt_min; /* :92 */
+  /* [nx] floyd_warshall: dist[u][u] = 0, the edges, then for w: for u: for v: d = dist[u][w] + dist[w][v]; if dist[u][v] > d */
+  double *D = e->fw;
+  for (size_t i = 0; i < (size_t)n * n; i++) D[i] = INFINITY;
+  for (int u = 0; u < n; u++) D[u * n + u] = 0.0;
+  for (int u = 0; u < n; u++) for (int k = 0; k < e->ucnt[u]; k++) { int v = e->uadj[u * n + k]; if (e->uw[u * n + v] < D[u * n + v]) D[u * n + v] = e->uw[u * n + v]; }
+  for (int w = 0; w < n; w++) for (int u = 0; u < n; u++) for (int v = 0; v < n; v++) { double d = D[u * n + w] + D[w * n + v]; if (D[u * n + v] > d) D[u * n + v] = d; }
+  for (int i = 0; i < np_; i++) {
+    int cnt = 0;
+    for (int v = 0; v < n; v++) if (!in_list5(e->pickups, np_, v) && !in_list5(e->dropoffs, np_, v)) e->q[cnt++] = v;
+    int p = e->q[np_randint(e->np, 0, cnt)]; /* np.random.choice(list) = list[randint(0, len)] */
+    e->pickups[i] = p;
+    /* keys of apsp[p] in dict order: p, neighbours below p ascending (G.edges reports an edge from its lower end), neighbours
+     * above p in adjacency insertion order, then the rest ascending (inserted by the reads of the w = 0 sweep) */
+    cnt = 0;
+    memset(e->tmp8, 0, n);
+    e->stk[cnt++] = p; e->tmp8[p] = 1;
+    for (int q = 0; q < p; q++) if (e->has[p * n + q]) { e->stk[cnt++] = q; e->tmp8[q] = 1; }
+    for (int k = 0; k < e->ucnt[p]; k++) { int q = e->uadj[p * n + k]; if (q > p) { e->stk[cnt++] = q; e->tmp8[q] = 1; } }
+    for (int q = 0; q < n; q++) if (!e->tmp8[q]) e->stk[cnt++] = q;
+    int nc = 0;
+    for (int k = 0; k < n; k++) { int v = e->stk[k]; if (D[p * n + v] < e->delivery_time + 1e-6 && !in_list5(e->pickups, np_, v) && !in_list5(e->dropoffs, np_, v)) e->q[nc++] = v; }
+    if (nc == 0) return 0;
+    e->dropoffs[i] = e->q[np_randint(e->np, 0, nc)];
+  }
+  return !in_list5(e->pickups, np_, -1) && !in_list5(e->dropoffs, np_, -1);
 }
 
 /* distribution_center.py:25-26: nodes whose shortest 'delay' distance from `s` is <= cutoff ([nx] the cutoff only prunes:
@@ -671,6 +714,7 @@ int oge_reset(oge_env *e, int64_t seed) {
     mt_init_genrand(e->np, s);
   }
   int ng = (t == OGE_DENSEST_SUBGRAPH) ? n - 1 : n; /* densest_subgraph.py:59-65 */
+  for (int i = 0; i < 5; i++) e->pickups[i] = e->dropoffs[i] = -1; /* perishable_product_delivery.py:72-73 */
   for (;;) {
     attempts++;
     gnm_random_graph(e, ng, m);
@@ -680,6 +724,10 @@ int oge_reset(oge_env *e, int64_t seed) {
       for (int v = 0; v < n; v++) if (e->ucnt[v] == 1) bad = 1;
       if (bad) continue;
       if (!is_connected_u(e, ng, 0)) continue;
+    }
+    if (t == OGE_PERISHABLE_DELIVERY) { /* perishable_product_delivery.py:82-111: weights and placement belong to the attempt */
+      delay_matrix_weights(e);
+      if (!perishable_place_products(e)) continue;
     }
     break;
   }
@@ -765,6 +813,24 @@ int oge_reset(oge_env *e, int64_t seed) {
     e->x[0 * F + 3] = 0.f;
     e->head = 0; e->mc_failed = 1;
     for (int p = 0; p < e->E; p++) { e->ef[2 * p] = (float)e->w64[p]; e->ef[2 * p + 1] = 0.f; }
+  } else if (t == OGE_PERISHABLE_DELIVERY) { /* perishable_product_delivery.py:114-166 */
+    build_directed(e);
+    int np_ = e->cfg.n_dests;
+    for (int i = 0; i < np_; i++) {
+      e->x[e->pickups[i] * F + 1 + i] = 1.f; e->x[e->dropoffs[i] * F + 6 + i] = 1.f;
+      for (int v = 0; v < n; v++) e->x[v * F + 11 + i] = (float)e->delivery_time;
+      e->terms[i] = e->pickups[i]; e->terms[np_ + i] = e->dropoffs[i];
+    }
+    e->n_targets = 2 * np_ - 1;
+    e->head = 0; e->x[0 * F + 0] = 1.f;
+    for (int p = 0; p < e->E; p++) e->ef[p] = (float)e->w64[p];
+    e->heuristic = 0.0;
+    if (e->cfg.is_eval_env) { /* :147-154; curr_node stays the head */
+      double total = 0.0;
+      for (int i = 0; i < np_; i++) { total += dijkstra(e, 0, e->pickups[i]); total += dijkstra(e, e->pickups[i], e->dropoffs[i]); }
+      e->heuristic = total;
+    }
+    e->cost_prev = 0.0;
   } else if (t == OGE_DISTRIBUTION_CENTER) { /* distribution_center.py:61-126 */
     delay_matrix_weights(e);
     build_directed(e);
@@ -866,6 +932,41 @@ int oge_step(oge_env *e, int64_t action, double *reward, int32_t *done, int32_t 
       if (missing == 0) { *done = 1; *solved = 1; }
       compute_mask(e);
       *reward = (double)r;
+      return OGE_OK;
+    }
+    case OGE_PERISHABLE_DELIVERY: { /* perishable_product_delivery.py:198-271 */
+      if (action < 0 || action >= n || !e->mask[action]) return OGE_INVALID_ACTION;
+      int a = (int)action, np_ = e->cfg.n_dests;
+      double r = 0.0;
+      e->cost_prev = e->cost64; /* info['solution_cost'] is read before the move (:213) */
+      e->edge_taken_cnt++;
+      if (a == e->head) { /* pick up: the only product waiting here (pickups are distinct, so np.random.choice draws nothing) */
+        int prod = -1;
+        for (int i = 0; i < np_; i++) if (e->x[e->head * F + 1 + i] == 1.f) { prod = i; break; }
+        for (int v = 0; v < n; v++) e->x[v * F + 1 + prod] = -1.f;
+        r += 2;
+      } else {
+        r = -e->adjw[e->head * n + a];
+        e->cost64 -= r;
+        e->x[e->head * F + 0] = 0.f; e->x[a * F + 0] = 1.f; e->head = a;
+        for (int i = 0; i < np_; i++) {
+          if (e->x[e->head * F + 1 + i] != -1.f) continue;
+          /* :241 subtracts adj[head, action] AFTER head became action: the diagonal, i.e. 0 -- the time never runs down */
+          float s = 0.f;
+          for (int v = 0; v < n; v++) { e->x[v * F + 11 + i] -= (float)e->adjw[e->head * n + a]; s += e->x[v * F + 11 + i]; }
+          if (s < 0 - 1e-6) { *done = 1; *solved = 0; *reward = -2.0 * n * np_; return OGE_OK; }
+          if (e->x[e->head * F + 6 + i] == 1.f) {
+            r += 2;
+            for (int v = 0; v < n; v++) { e->x[v * F + 1 + i] = 0.f; e->x[v * F + 6 + i] = 0.f; e->x[v * F + 11 + i] = 0.f; }
+          }
+        }
+      }
+      float hs = 0.f;
+      for (int v = 0; v < n; v++) for (int i = 0; i < 5; i++) hs += e->x[v * F + 1 + i];
+      if (hs == 0.f) { *done = 1; *solved = 1; r += 2 * n; }
+      else if (e->edge_taken_cnt >= (int64_t)n * np_ * 50) { *done = 1; *solved = 0; r = -2.0 * n * np_; }
+      compute_mask(e);
+      *reward = r;
       return OGE_OK;
     }
     case OGE_DISTRIBUTION_CENTER: { /* distribution_center.py:144-178 */
@@ -980,6 +1081,7 @@ void oge_get_features64(const oge_env *e, double *sf) { memcpy(sf, e->sf64, (siz
 double oge_solution_cost(const oge_env *e) {
   int t = e->cfg.env_type;
   if (t == OGE_MULTICAST_ROUTING) return e->mc_failed ? -1.0 : (double)e->cost32; /* multicast_routing.py:203,262 */
+  if (t == OGE_PERISHABLE_DELIVERY) return e->cost_prev; /* perishable_product_delivery.py:213 */
   return (t == OGE_STEINER_TREE || t == OGE_MAX_INDEPENDENT_SET || t == OGE_DISTRIBUTION_CENTER) ? (double)e->cost32 : e->cost64;
 }
 double oge_heuristic_solution(const oge_env *e) { return e->heuristic; }

@@ -21,7 +21,7 @@ extern "C" {
 
 enum { OGE_SHORTEST_PATH = 0, OGE_LONGEST_PATH = 1, OGE_STEINER_TREE = 2, OGE_TSP = 3,
        OGE_DENSEST_SUBGRAPH = 4, OGE_MAX_INDEPENDENT_SET = 5, OGE_MULTICAST_ROUTING = 6,
-       OGE_DISTRIBUTION_CENTER = 7 };
+       OGE_DISTRIBUTION_CENTER = 7, OGE_PERISHABLE_DELIVERY = 8 };
 
 typedef struct {
   int32_t env_type;
@@ -29,11 +29,13 @@ typedef struct {
   int32_t n_edges;
   int32_t weighted;
   int32_t parenting;
-  int32_t n_dests;     /* SteinerTree, MulticastRouting; DistributionCenter: target_count */
+  int32_t n_dests;     /* SteinerTree, MulticastRouting; DistributionCenter: target_count; PerishableProductDelivery: n_products */
   int32_t spatial;     /* TSP only */
   int32_t is_eval_env;
   double n_choices;    /* DensestSubgraph only; <0 -> n_nodes // e (reference default) */
   double max_distance; /* DistributionCenter only (distribution_center.py:29) */
+  double dt_min, dt_max; /* PerishableProductDelivery: delivery-time window, computed by the constructor with numpy
+                            (perishable_product_delivery.py:53-61) */
 } oge_cfg;
 
 typedef struct oge_env oge_env;

@@ -80,6 +80,13 @@ CASES = {
     "dc_n64_m192_p2_dist0p7": ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192, max_distance=0.7, target_count=20), list(range(4))),
     "dc_n200_m600_p2": ("DistributionCenter-v0", dict(n_nodes=200, n_edges=600), [0, 1]),
     "dc_n300_m900_p1_dist2": ("DistributionCenter-v0", dict(n_nodes=300, n_edges=900, parenting=1, max_distance=2), [0]),
+    # PerishableProductDelivery (perishable_product_delivery.py); parenting must be 1
+    "ppd_n10_m20": ("PerishableProductDelivery-v0", dict(n_nodes=10, n_edges=20, parenting=1), list(range(10))),
+    "ppd_n12_m30_p5_eval": ("PerishableProductDelivery-v0", dict(n_nodes=12, n_edges=30, n_products=5, parenting=1, is_eval_env=True), list(range(6))),
+    "ppd_n8_m9_p3": ("PerishableProductDelivery-v0", dict(n_nodes=8, n_edges=9, parenting=1), list(range(12))),
+    "ppd_n12_auto_unweighted": ("PerishableProductDelivery-v0", dict(n_nodes=12, n_edges=-1, weighted=False, n_products=2, parenting=1), list(range(4))),
+    "ppd_n64_m192_eval": ("PerishableProductDelivery-v0", dict(n_nodes=64, n_edges=192, parenting=1, is_eval_env=True), list(range(4))),
+    "ppd_n100_m300_p4": ("PerishableProductDelivery-v0", dict(n_nodes=100, n_edges=300, n_products=4, parenting=1), [0, 1]),
     "mc_n300_m900_p3_d4_eval": ("MulticastRouting-v0", dict(n_nodes=300, n_edges=900, n_dests=4, parenting=3, is_eval_env=True), [0]),
 }
 
@@ -106,12 +113,14 @@ def terminals_of(env, env_id):
         return [0]
     if env_id == "MulticastRouting-v0":
         return [int(env.src)] + [int(d) for d in env.dests]
+    if env_id == "PerishableProductDelivery-v0":
+        return [int(v) for v in env.pickups] + [int(v) for v in env.dropoffs]
     if env_id == "DistributionCenter-v0":
         return [int(t) for t in env.in_range_dict]  # targets, in the order they were drawn
     return []
 
 
-def roll(gym, env_id, kwargs, seed, policy, max_steps=100000):
+def roll(gym, env_id, kwargs, seed, policy, max_steps=4000):
     env = gym.make(env_id, **kwargs)
     obs, info = env.reset(seed=seed)
     rec = dict(reset_obs=obs.copy(), reset_mask=info["mask"].copy(), terminals=terminals_of(env, env_id))

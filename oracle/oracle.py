@@ -21,6 +21,7 @@ ENV_TYPES = {
     "MaxIndependentSet-v0": 5,
     "MulticastRouting-v0": 6,
     "DistributionCenter-v0": 7,
+    "PerishableProductDelivery-v0": 8,
 }
 
 
@@ -29,6 +30,7 @@ class OgeCfg(C.Structure):
         ("env_type", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
         ("weighted", C.c_int32), ("parenting", C.c_int32), ("n_dests", C.c_int32),
         ("spatial", C.c_int32), ("is_eval_env", C.c_int32), ("n_choices", C.c_double), ("max_distance", C.c_double),
+        ("dt_min", C.c_double), ("dt_max", C.c_double),
     ]
 
 
@@ -87,20 +89,30 @@ def lib():
 
 
 def make_cfg(env_id, n_nodes, n_edges=-1, weighted=None, parenting=None, n_dests=3, spatial=False,
-             is_eval_env=False, n_choices=-1, max_distance=1, target_count=-1, **_ignored) -> OgeCfg:
+             is_eval_env=False, n_choices=-1, max_distance=1, target_count=-1, n_products=3, delivery_time=-1, **_ignored) -> OgeCfg:
     t = ENV_TYPES[env_id]
     if parenting is None:
         parenting = 4 if t == 6 else -1  # multicast_routing.py:31
     if n_edges == -1:
-        assert t == 6, "n_edges is required"
+        assert t in (6, 8), "n_edges is required"
         n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # multicast_routing.py:53-54
     if weighted is None:
         weighted = (t != 4)  # DensestSubgraph defaults to weighted=False (densest_subgraph.py:25)
+    dt = (0.0, 0.0)
+    if t == 8:  # perishable_product_delivery.py:27,34,53-61
+        assert parenting in [1], "Parenting must be 1!"
+        assert n_products <= 5, "Max 5 products!"
+        assert delivery_time == -1, "the reference only runs with delivery_time=-1"
+        n_dests = n_products
+        avg_dist = np.log(n_nodes) / np.log(2 * n_edges / n_nodes)
+        if weighted:
+            avg_dist = avg_dist * (0.3 + 1.0) / 2.0
+        dt = (float(avg_dist * 0.6), float(avg_dist * 1.4))
     if t == 7:  # distribution_center.py:29,42-45
         parenting = 2 if parenting == -1 else parenting
         n_dests = n_nodes // 5 if target_count == -1 else target_count
     return OgeCfg(t, n_nodes, n_edges, int(bool(weighted)), int(parenting), int(n_dests),
-                  int(bool(spatial)), int(bool(is_eval_env)), float(n_choices), float(max_distance))
+                  int(bool(spatial)), int(bool(is_eval_env)), float(n_choices), float(max_distance), *dt)
 
 
 class OracleEnv:
