@@ -24,6 +24,7 @@ ENV_TYPES = {
     "MaxIndependentSet-v0": 5,
     "MulticastRouting-v0": 6,
     "DistributionCenter-v0": 7,
+    "PerishableProductDelivery-v0": 8,
 }
 
 
@@ -33,7 +34,7 @@ class GeConfig(C.Structure):
         ("weighted", C.c_int32), ("parenting", C.c_int32), ("n_dests", C.c_int32), ("spatial", C.c_int32),
         ("is_eval_env", C.c_int32), ("autoreset", C.c_int32), ("n_choices", C.c_double),
         ("env_index_base", C.c_int64), ("seed_stride", C.c_int64), ("node_id_base", C.c_int64),
-        ("edge_row_stride", C.c_int64), ("max_distance", C.c_double),
+        ("edge_row_stride", C.c_int64), ("max_distance", C.c_double), ("dt_min", C.c_double), ("dt_max", C.c_double),
     ]
 
 

@@ -37,7 +37,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (!cfg) return fail(GE_E_BADARG, "null config");
   memset(&P, 0, sizeof(P));
   const int t = cfg->env_type, n = cfg->n_nodes, m = cfg->n_edges;
-  if (t < GE_SHORTEST_PATH || t > GE_DISTRIBUTION_CENTER) return fail(GE_E_BADARG, "unknown env_type");
+  if (t < GE_SHORTEST_PATH || t > GE_PERISHABLE_DELIVERY) return fail(GE_E_BADARG, "unknown env_type");
   if (cfg->num_envs < 1) return fail(GE_E_BADARG, "num_envs must be >= 1");
   if (n < 3 || n > 4095) return fail(GE_E_BADARG, "n_nodes must be in [3, 4095]");
   const int ng = (t == GE_DENSEST_SUBGRAPH) ? n - 1 : n;  // densest_subgraph.py:59
@@ -53,6 +53,10 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (t == GE_DENSEST_SUBGRAPH && cfg->weighted) return fail(GE_E_BADARG, "Weighted graphs not supported for this env (densest_subgraph.py:29)");
   if (t == GE_TSP && cfg->spatial && !cfg->weighted) return fail(GE_E_BADARG, "Spatial TSP must be weighted (tsp.py:27)");
   if ((t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING) && (cfg->n_dests < 1 || cfg->n_dests > n - 1)) return fail(GE_E_BADARG, "n_dests must be in [1, n_nodes-1]");
+  if (t == GE_PERISHABLE_DELIVERY && cfg->parenting != 1) return fail(GE_E_BADARG, "Parenting must be 1! (perishable_product_delivery.py:30)");
+  if (t == GE_PERISHABLE_DELIVERY && (cfg->n_dests < 1 || cfg->n_dests > 5)) return fail(GE_E_BADARG, "Max 5 products! (perishable_product_delivery.py:35)");
+  if (t == GE_PERISHABLE_DELIVERY && 2 * cfg->n_dests > n) return fail(GE_E_BADARG, "2 * n_products exceeds n_nodes: the reference would loop forever");
+  if (t == GE_PERISHABLE_DELIVERY && !(cfg->dt_max >= cfg->dt_min && cfg->dt_min > 0.0)) return fail(GE_E_BADARG, "dt_min / dt_max must be the constructor's delivery-time window (0 < dt_min <= dt_max)");
   if (t == GE_DISTRIBUTION_CENTER && cfg->parenting != 1 && cfg->parenting != 2) return fail(GE_E_BADARG, "parenting must be 1 or 2 (distribution_center.py:32)");
   if (t == GE_DISTRIBUTION_CENTER && (cfg->n_dests < 0 || cfg->n_dests > n)) return fail(GE_E_BADARG, "target_count must be in [0, n_nodes]");
   if (t == GE_DISTRIBUTION_CENTER && !(cfg->max_distance >= 0.0)) return fail(GE_E_BADARG, "max_distance must be >= 0");
@@ -63,13 +67,14 @@ static int derive(const ge_config *cfg, GeParams &P) {
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
   const bool edge_env = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
-  P.nflag = (t == GE_TSP || t == GE_MULTICAST_ROUTING) ? 4 : (t == GE_DENSEST_SUBGRAPH ? 1 : (t == GE_DISTRIBUTION_CENTER ? 5 : 2));  // utils.py:32-73
+  P.nflag = (t == GE_TSP || t == GE_MULTICAST_ROUTING) ? 4 : (t == GE_DENSEST_SUBGRAPH ? 1 : (t == GE_DISTRIBUTION_CENTER ? 5 : (t == GE_PERISHABLE_DELIVERY ? 16 : 2)));  // utils.py:32-73
   P.F = P.nflag + 5;
   P.Fe = edge_env ? 2 : 1;
   P.A = edge_env ? P.E : n;  // steiner_tree.py:117, multicast_routing.py:155-157
   P.AW = (P.A + 63) / 64;
   P.T = edge_env ? (cfg->n_dests + 1 > 2 ? cfg->n_dests + 1 : 2) : 2;
   if (t == GE_DISTRIBUTION_CENTER) { P.T = cfg->n_dests > 2 ? cfg->n_dests : 2; P.max_distance = cfg->max_distance; }
+  if (t == GE_PERISHABLE_DELIVERY) { P.T = 2 * cfg->n_dests; P.dt_min = cfg->dt_min; P.dt_max = cfg->dt_max; }
   P.weighted = cfg->weighted ? 1 : 0; P.parenting = cfg->parenting; P.n_dests = cfg->n_dests;
   P.spatial = (t == GE_TSP && cfg->spatial) ? 1 : 0;
   P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset ? 1 : 0;

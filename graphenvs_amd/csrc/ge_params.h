@@ -32,6 +32,7 @@ struct GeLds {
   int f64a;     // f64[2][n] Dijkstra distances (sigma, delta); also stages the first mask words
   int bits;     // u64[6][W] frontier / visited / next / removed-or-targets / prune / removed (first mask)
   int misc;     // i32[16]
+  int fw;       // f64[n*n]  PerishableProductDelivery: Floyd-Warshall matrix (else absent)
   int pre;      // i32[nblk+1] exclusive prefix of the per-workgroup reset counts
   int total;
 };
@@ -51,6 +52,7 @@ struct GeParams {
   int32_t cost_off;  // DistributionCenter: byte offset of the node-cost list inside the wm scratch
   double n_choices;
   double max_distance;  // DistributionCenter coverage radius
+  double dt_min, dt_max;  // PerishableProductDelivery delivery-time window
   int64_t env_index_base, seed_stride, node_id_base, edge_row_stride;
   ge_buffers buf;
   GeLds lds;
@@ -82,6 +84,7 @@ static inline void ge_make_lds(GeParams &P) {
   { int need = 2 * P.n * 8, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
   L.bits = take(6 * P.W * 8);
   L.misc = take(16 * 4);
+  L.fw = (P.env_type == GE_PERISHABLE_DELIVERY) ? take(P.n * P.n * 8) : 0;
   // the queue prefix is only needed while a workgroup looks up its slot: it overlays the scratch that follows
   { int pb = ((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4; L.pre = L.mt; if (pb > GE_MT_N * 8) { L.pre = take(pb); } }
   L.total = o;

@@ -470,6 +470,104 @@ GE_DEV double ge_multicast_baseline(const GeParams &P, const GeRctx &c, int env,
   return total;
 }
 
+// one 32-bit numpy draw, wave-uniform (every lane reads the same word)
+GE_DEV uint32_t ge_np_next(uint32_t *mt, int &nppos, int lane) {
+  if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+  const uint32_t r = ge_temper(mt[nppos]); nppos++;
+  return r;
+}
+// [np] legacy randint(0, cnt) for cnt >= 1 (what np.random.choice(list) draws its index with): masked rejection,
+// nothing is drawn when cnt == 1
+GE_DEV int ge_np_index(uint32_t *mt, int &nppos, int cnt, int lane) {
+  if (cnt <= 1) return 0;
+  const uint32_t rng = (uint32_t)(cnt - 1), mask = ge_mask_below(rng);
+  for (;;) { const uint32_t v = ge_np_next(mt, nppos, lane) & mask; if (v <= rng) return (int)v; }
+}
+// index of the k-th set bit (k from 0) of a two-word set; the caller guarantees it exists
+GE_DEV int ge_select2(uint64_t w0, uint64_t w1, int k) {
+  const int c0 = ge_popc64(w0);
+  uint64_t w = w0; int base = 0;
+  if (k >= c0) { w = w1; k -= c0; base = 64; }
+  for (int j = 0; j < k; j++) w &= w - 1;
+  return base + ge_ctz64(w);
+}
+
+// perishable_product_delivery.py:92-108, one attempt on a connected graph whose delay matrix is in the nibble matrix:
+// delivery_time = rand() * (dt_max - dt_min) + dt_min; apsp = floyd_warshall; per product a pickup among the unused nodes
+// and a drop-off among the unused nodes closer than delivery_time + 1e-6, listed in the key order of the apsp[pickup]
+// dict ([nx] floyd_warshall builds defaultdicts: the node itself, the neighbours below it ascending -- G.edges reports
+// an edge from its lower end --, the neighbours above it in adjacency insertion order, then every other node ascending,
+// inserted by the reads of the first sweep).  pk / dp persist over failed attempts, as self.pickups / self.dropoffs do.
+// Returns false when a pickup has no drop-off in range.  n <= 128 (two-word node sets); wave-uniform control flow.
+GE_DEV bool ge_ppd_place(const GeParams &P, const GeRctx &c, double *D, double rnd, int &nppos, int *pk, int *dp, double &dt_out, int lane) {
+  const int n = P.n, m = P.m, np_ = P.n_dests;
+  const double dt = rnd * (P.dt_max - P.dt_min) + P.dt_min;
+  dt_out = dt;
+  for (int idx = lane; idx < n * n; idx += GE_WAVE) {
+    const int u = idx / n, v = idx - u * n;
+    double w = __builtin_inf();
+    if (u == v) w = 0.0;
+    else if ((c.abits[u * P.W + (v >> 6)] >> (v & 63)) & 1ull) {
+      const int cell = (u < v ? u : v) * n + (u < v ? v : u);
+      w = P.weighted ? ge_wlut((int)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u)) : 1.0;
+    }
+    D[idx] = w;
+  }
+  ge_wave_sync();
+  for (int w = 0; w < n; w++) {  // row w and column w do not change during sweep w (x + 0 == x, strict >): the cells are independent
+    for (int idx = lane; idx < n * n; idx += GE_WAVE) {
+      const int u = idx / n, v = idx - u * n;
+      const double d = D[u * n + w] + D[w * n + v];
+      if (D[idx] > d) D[idx] = d;
+    }
+    ge_wave_sync();
+  }
+  for (int i = 0; i < np_; i++) {
+    uint64_t used0 = 0, used1 = 0;
+    for (int j = 0; j < np_; j++) {
+      if (pk[j] >= 0) { if (pk[j] < 64) used0 |= 1ull << pk[j]; else used1 |= 1ull << (pk[j] - 64); }
+      if (dp[j] >= 0) { if (dp[j] < 64) used0 |= 1ull << dp[j]; else used1 |= 1ull << (dp[j] - 64); }
+    }
+    const uint64_t all0 = n >= 64 ? ~0ull : ((1ull << n) - 1ull), all1 = n <= 64 ? 0ull : (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1ull));
+    const uint64_t f0 = all0 & ~used0, f1 = all1 & ~used1;
+    const int p = ge_select2(f0, f1, ge_np_index(c.mt2, nppos, ge_popc64(f0) + ge_popc64(f1), lane));
+    pk[i] = p;  // replaces what a failed attempt may have left in this entry: the used set is rebuilt
+    used0 = 0; used1 = 0;
+    for (int j = 0; j < np_; j++) {
+      if (pk[j] >= 0) { if (pk[j] < 64) used0 |= 1ull << pk[j]; else used1 |= 1ull << (pk[j] - 64); }
+      if (dp[j] >= 0) { if (dp[j] < 64) used0 |= 1ull << dp[j]; else used1 |= 1ull << (dp[j] - 64); }
+    }
+    const uint64_t pass0 = ge_ballot(lane < n && D[p * n + lane] < dt + 1e-6) & ~used0;
+    const uint64_t pass1 = (n > 64 ? ge_ballot(lane + 64 < n && D[p * n + lane + 64] < dt + 1e-6) : 0ull) & ~used1;
+    const uint64_t nb0 = c.abits[p * P.W], nb1 = P.W > 1 ? c.abits[p * P.W + 1] : 0ull;
+    const uint64_t lo0 = p < 64 ? ((1ull << p) - 1ull) : ~0ull, lo1 = p < 64 ? 0ull : ((1ull << (p - 64)) - 1ull);  // nodes below p
+    const uint64_t B0 = pass0 & nb0 & lo0, B1 = pass1 & nb1 & lo1;          // neighbours below p, ascending
+    const uint64_t C0 = pass0 & nb0 & ~lo0, C1 = pass1 & nb1 & ~lo1;        // neighbours above p, adjacency insertion order
+    const uint64_t R0 = pass0 & ~nb0, R1 = pass1 & ~nb1;                    // the rest, ascending (p itself is used)
+    const int nB = ge_popc64(B0) + ge_popc64(B1), nC = ge_popc64(C0) + ge_popc64(C1), nR = ge_popc64(R0) + ge_popc64(R1);
+    if (nB + nC + nR == 0) return false;
+    int k = ge_np_index(c.mt2, nppos, nB + nC + nR, lane);
+    int d;
+    if (k < nB) d = ge_select2(B0, B1, k);
+    else if (k < nB + nC) {  // the (k - nB)-th edge of p, in insertion order, whose other end is in C
+      k -= nB; d = -1;
+      for (int e0 = 0; e0 < m && d < 0; e0 += GE_WAVE) {
+        const int e = e0 + lane;
+        int other = -1;
+        if (e < m) { const uint32_t uv = c.elist[e]; const int u = (int)(uv & 0xffffu), v = (int)(uv >> 16); other = (u == p) ? v : ((v == p) ? u : -1); }
+        const bool hit = other >= 0 && (((other < 64 ? C0 : C1) >> (other & 63)) & 1ull);
+        const uint64_t H = ge_ballot(hit);
+        const int cnt = ge_popc64(H);
+        if (k < cnt) { uint64_t hh = H; for (int j = 0; j < k; j++) hh &= hh - 1; d = ge_shfl_i32(other, ge_ctz64(hh)); }
+        else k -= cnt;
+      }
+    } else d = ge_select2(R0, R1, k - nB - nC);
+    dp[i] = d;
+  }
+  for (int j = 0; j < np_; j++) if (pk[j] < 0 || dp[j] < 0) return false;
+  return true;
+}
+
 // MulticastRouting tail of the numpy stream (multicast_routing.py:98,106): dests = arange(1, n)[permutation(n - 1)[:k]],
 // then ONE rand() for max_distance.  Leaves perm[0] = 0 (the source), perm[1..k] = dests and the rand in misc[0..1].
 GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
@@ -503,7 +601,8 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
   GE_STAMP(21);
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
-  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER);
+  const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER ||
+                          t == GE_PERISHABLE_DELIVERY);
   if (P.spatial) {  // tsp.py:81-83: x, y = np.random.rand() * 10 per node; rand() = two 32-bit draws, no rejection
     uint32_t *raw = c.wm; double *xy = (double *)(c.wm + 4 * n);
     for (int p0 = 0; p0 < 4 * n; p0 += GE_WAVE) {
@@ -529,6 +628,12 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
   }
   GE_STAMP(22);
   if (t == GE_DISTRIBUTION_CENTER) ge_np_draws(P, c, c.mt2, nppos, n, lane, 3);  // node costs, weighted or not
+  if (t == GE_PERISHABLE_DELIVERY) {  // first attempt: delay matrix, then the rand() of delivery_time; the rest needs the topology
+    const uint32_t ra = ge_np_next(c.mt2, nppos, lane), rb = ge_np_next(c.mt2, nppos, lane);
+    if (lane == 0) { *(double *)c.misc = ((double)(int32_t)(ra >> 5) * 67108864.0 + (double)(int32_t)(rb >> 6)) / 9007199254740992.0; c.misc[2] = nppos; }
+    ge_wave_sync();
+    return;
+  }
   if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
   else if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane, n);
   GE_STAMP(23);
@@ -545,6 +650,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   GeRctx c = ge_carve(P);
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   int src = 0, dest = -1;
+  int ppd_pk[5] = {-1, -1, -1, -1, -1}, ppd_dp[5] = {-1, -1, -1, -1, -1};  // perishable_product_delivery.py:72-73
+  double ppd_dt = 0.0;
   if (wv == 1) {
     if (mode != GE_RESET_INJECT) { ge_numpy_wave(P, c, env, lane); ge_sync(); }
     ge_sync();
@@ -557,6 +664,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     ge_mt_load(c.mt, P.buf.mt_state + (int64_t)env * 2 * GE_MT_N, lane);  // pre-seeded (ge_k_seed)
     GE_STAMP(1);
     int pypos = GE_MT_N;
+    int ppd_attempt = 0, ppd_pos = 0;  // PerishableProductDelivery: the numpy stream is continued by this wave after the join
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
     for (;;) {
       for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
@@ -650,6 +758,17 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         ok = !deg1;
         if (ok) ok = ge_connected(c, ng, W, 0, lane);
       }
+      if (ok && t == GE_PERISHABLE_DELIVERY) {  // perishable_product_delivery.py:75-111: weights and placement belong to the attempt
+        double rnd;
+        if (ppd_attempt == 0) { ge_sync(); ppd_pos = c.misc[2]; rnd = *(const double *)c.misc; }  // join: the numpy wave drew the first matrix and rand()
+        else {
+          if (P.weighted) { for (int i = lane; i < (n * n + 7) / 8; i += GE_WAVE) c.wm[i] = 0u; ge_wave_sync(); ge_np_draws(P, c, c.mt2, ppd_pos, n * n, lane, 0); }
+          const uint32_t ra = ge_np_next(c.mt2, ppd_pos, lane), rb = ge_np_next(c.mt2, ppd_pos, lane);
+          rnd = ((double)(int32_t)(ra >> 5) * 67108864.0 + (double)(int32_t)(rb >> 6)) / 9007199254740992.0;
+        }
+        ppd_attempt++;
+        ok = ge_ppd_place(P, c, (double *)(ge_dyn_smem() + P.lds.fw), rnd, ppd_pos, ppd_pk, ppd_dp, ppd_dt, lane);
+      }
       if (ok) break;
     }
   } else {
@@ -666,7 +785,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
 
   GE_STAMP(2);
-  if (mode != GE_RESET_INJECT) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
+  if (mode != GE_RESET_INJECT && t != GE_PERISHABLE_DELIVERY) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
   // ------------------------------------------------------------------ CSR in insertion order
   if (mode != GE_RESET_INJECT) {
     for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
@@ -727,7 +846,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
     ge_wave_sync();
     const bool path_like = path_like_t;
-    const bool matrix_w = path_like_t || t == GE_DISTRIBUTION_CENTER;  // delay[u, v] of an n x n randint matrix
+    const bool matrix_w = path_like_t || t == GE_DISTRIBUTION_CENTER || t == GE_PERISHABLE_DELIVERY;  // delay[u, v] of an n x n randint matrix
     if (P.weighted && matrix_w && P.np_early) {  // delay[u, v], u < v, from the nibble matrix the numpy wave filled
       for (int idx = lane; idx < E; idx += GE_WAVE) {
         int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
@@ -772,13 +891,17 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     ge_wave_sync();
     GE_STAMP(5);
     if (path_like) { src = c.perm[0]; dest = c.perm[1]; }  // multicast: perm[0] = 0 (multicast_routing.py:97)
+    if (t == GE_PERISHABLE_DELIVERY) {
+      if (lane < P.n_dests) { c.perm[lane] = ppd_pk[lane]; c.perm[P.n_dests + lane] = ppd_dp[lane]; }
+      ge_wave_sync();
+    }
   } else {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
       c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)(c.colw[idx] & 15);
     }
     ge_wave_sync();
-    if (path_like_t || t == GE_DISTRIBUTION_CENTER) {
+    if (path_like_t || t == GE_DISTRIBUTION_CENTER || t == GE_PERISHABLE_DELIVERY) {
       for (int k = lane; k < T; k += GE_WAVE) c.perm[k] = inj.terminals[(int64_t)env * T + k];
       ge_wave_sync();
       if (path_like_t) { src = c.perm[0]; dest = c.perm[1]; }
@@ -826,6 +949,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : kNaN;  // greedy MIS not built
     else if (t == GE_MULTICAST_ROUTING) heuristic = 0.0;                 // computed below, after the delay bound
     else if (t == GE_DISTRIBUTION_CENTER) heuristic = -1.0;              // distribution_center.py:91
+    else if (t == GE_PERISHABLE_DELIVERY) heuristic = 0.0;               // computed below
     else heuristic = kNaN;                                              // Kou / Christofides not built
   }
 
@@ -847,6 +971,21 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
 
   if (t == GE_DISTRIBUTION_CENTER) heuristic = -1.0;  // distribution_center.py:91, eval or not
+  if (mode != GE_RESET_INJECT && t == GE_PERISHABLE_DELIVERY) {
+    heuristic = 0.0;
+    if (P.is_eval) {  // perishable_product_delivery.py:147-154: curr_node stays the head; total += a; total += b
+      double d0[5];
+      ge_dijkstra_wave(c, n, 0, lane);
+      for (int i = 0; i < P.n_dests; i++) d0[i] = c.sigma[c.perm[i]];
+      ge_wave_sync();
+      for (int i = 0; i < P.n_dests; i++) {
+        ge_dijkstra_wave(c, n, c.perm[i], lane);
+        heuristic += d0[i];
+        heuristic += c.sigma[c.perm[P.n_dests + i]];
+        ge_wave_sync();
+      }
+    }
+  }
   GE_STAMP(9);
   // ------------------------------------------------------------------ write the slot to HBM
   const ge_buffers &G = P.buf;
@@ -873,6 +1012,14 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       else if (t == GE_MAX_INDEPENDENT_SET) val = (col == 0) ? (float)ge_wlut(c.fill[v]) : 0.f;
       else if (t == GE_MULTICAST_ROUTING)  // HAS_MSG, IS_TARGET, MAX_DISTANCE, DISTANCE_FROM_SOURCE (multicast_routing.py:124-129)
         val = (col == 0) ? (v == src ? 1.f : 0.f) : (col == 1) ? (is_t ? 1.f : 0.f) : (col == 2) ? (float)max_distance : (v == src ? 0.f : -1.f);
+      else if (t == GE_PERISHABLE_DELIVERY) {  // IS_HEAD, HAS_P[5], NEEDS_P[5], TIME_LEFT_P[5] (perishable_product_delivery.py:118-131)
+        const int pi = (col - 1) % 5;
+        if (col == 0) val = (v == 0) ? 1.f : 0.f;
+        else if (pi >= P.n_dests) val = 0.f;
+        else if (col <= 5) val = (v == c.perm[pi]) ? 1.f : 0.f;
+        else if (col <= 10) val = (v == c.perm[P.n_dests + pi]) ? 1.f : 0.f;
+        else val = (float)ppd_dt;
+      }
       else if (t == GE_DISTRIBUTION_CENTER)  // WEIGHT, IS_TAKEN, IS_TARGET, IS_COVERED, MAX_DISTANCE (distribution_center.py:99-102)
         val = (col == 0) ? (float)((const uint8_t *)c.wm)[P.cost_off + v] : (col == 2) ? (is_t ? 1.f : 0.f) : (col == 4) ? (float)P.max_distance : 0.f;
       G.x[(nbase + v) * F + col] = val;
@@ -953,6 +1100,10 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;
     uint64_t full = (hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull);
     if (t == GE_SHORTEST_PATH || (t == GE_LONGEST_PATH && P.parenting != 0) || t == GE_TSP) mb = c.abits[src * W + w] & prune[w];
+    else if (t == GE_PERISHABLE_DELIVERY) {  // neighbours of the head, and the head itself if a product waits there (:176-181)
+      mb = c.abits[0 * W + w];
+      if (w == 0) for (int i = 0; i < P.n_dests; i++) if (c.perm[i] == 0) mb |= 1ull;
+    }
     else if (t == GE_STEINER_TREE || (t == GE_MULTICAST_ROUTING && P.parenting >= 2)) {  // edges leaving src: steiner_tree.py:116-120;
       // multicast_routing.py:155-186: parenting 2 the same; parenting >= 3 keeps, per outside node, its best tree edge, and
       // with only the source in the tree that is the one edge from the source

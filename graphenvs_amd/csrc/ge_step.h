@@ -78,6 +78,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
     uint8_t st = G.status[i];
     double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
     bool cost_hidden = false;  // multicast: info['solution_cost'] stays -1 unless the episode is solved
+    bool cost_lagged = false; double cost_before = 0.0;  // perishable delivery: info['solution_cost'] is read before the move
     if (st != 0 || a64 == -1) {
       // frozen slot (finished, autoreset off) or explicit no-op: nothing moves
     } else {
@@ -276,6 +277,51 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
           else if (!any) { done = 1; solved = 0; reward = fail; }
           break;
         }
+        case GE_PERISHABLE_DELIVERY: {  // perishable_product_delivery.py:198-271
+          if (!mbit) { invalid = 1; break; }
+          acted = true; cost_lagged = true; cost_before = G.cost[i];
+          const int np_ = P.n_dests;
+          const int32_t *term = G.terminals + (int64_t)i * P.T;  // pickups, then drop-offs
+          int pst = G.counters[i * 2];                            // 2 bits per product: 0 waiting, 1 carried, 2 delivered
+          int now = head;
+          if (a == head) {  // pick up the product waiting here (pickups are distinct nodes, so np.random.choice has one candidate and draws nothing)
+            int prod = -1;
+            for (int p = 0; p < np_; p++) if (prod < 0 && term[p] == head && ((pst >> (2 * p)) & 3) == 0) prod = p;
+            pst |= 1 << (2 * prod);
+            for (int v = 0; v < n; v++) G.x[(nbase + v) * F + 1 + prod] = -1.f;  // the whole HAS_P column (:224)
+            reward = 2.0;
+          } else {
+            const double wgt = ge_wlut(ge_edge_code(P, i, head, a));
+            reward = -wgt;
+            G.cost[i] = cost_before + wgt;
+            G.x[(nbase + head) * F + 0] = 0.f; G.x[(nbase + a) * F + 0] = 1.f;
+            G.head[i] = a; now = a;
+            // :241 subtracts adj[head, action] after head became action -- the zero diagonal -- so TIME_LEFT never runs down
+            for (int p = 0; p < np_; p++)
+              if (((pst >> (2 * p)) & 3) == 1 && term[np_ + p] == a) {  // delivered
+                reward += 2.0;
+                pst = (pst & ~(3 << (2 * p))) | (2 << (2 * p));
+                for (int v = 0; v < n; v++) { G.x[(nbase + v) * F + 1 + p] = 0.f; G.x[(nbase + v) * F + 6 + p] = 0.f; G.x[(nbase + v) * F + 11 + p] = 0.f; }
+              }
+          }
+          G.counters[i * 2] = pst;
+          int hs = 0;  // x[:, HAS_P].sum(): 1 per waiting product, -n per carried one
+          bool waits_here = false;
+          for (int p = 0; p < np_; p++) {
+            const int s2 = (pst >> (2 * p)) & 3;
+            hs += (s2 == 0) ? 1 : (s2 == 1 ? -n : 0);
+            if (s2 == 0 && term[p] == now) waits_here = true;
+          }
+          if (hs == 0) { done = 1; solved = 1; reward += 2.0 * n; }
+          else if (G.counters[i * 2 + 1] + 1 >= n * np_ * 50) { done = 1; solved = 0; reward = -2.0 * n * np_; }  // max_steps
+          for (int w = 0; w < W; w++) {
+            uint64_t nm = G.adj_bits[(nbase + now) * W + w];
+            if (waits_here && (now >> 6) == w) nm |= 1ull << (now & 63);
+            stage[tid * W + w] = nm;
+          }
+          wrote_mask = true;
+          break;
+        }
         case GE_DISTRIBUTION_CENTER: {  // distribution_center.py:144-178
           if (!mbit) { invalid = 1; break; }
           acted = true;
@@ -365,7 +411,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
       if (!(t == GE_DENSEST_SUBGRAPH || t == GE_TSP)) { len += 1; G.counters[i * 2 + 1] = len; }
       G.tstep[i] = G.tstep[i] + 1;
       if (done) {
-        G.final_cost[i] = cost_hidden ? -1.0 : G.cost[i];
+        G.final_cost[i] = cost_hidden ? -1.0 : (cost_lagged ? cost_before : G.cost[i]);
         G.final_heur[i] = G.heuristic[i];
         G.final_len[i] = len;
         if (P.autoreset) {

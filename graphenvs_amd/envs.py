@@ -29,6 +29,7 @@ class GraphEnv:
         """reset(seed=s) reproduces the reference's reset(seed=s).  seed=None moves to the slot's next
         episode seed (the reference would continue the process-global streams instead)."""
         obs, info = self._v.reset(seed=None if seed is None else [int(seed)])
+        self._last_cost = np.float64(0.0)
         return self._np(obs)[0].copy(), {"mask": self._np(info["mask"])[0].copy()}
 
     def step(self, action):
@@ -44,6 +45,10 @@ class GraphEnv:
             out["solved"] = bool(solved)
         if self.env_id == "MulticastRouting-v0":  # both keys on every step; the cost is -1 unless solved (multicast_routing.py:202-203,262)
             out["solution_cost"] = np.float32(self._np(self._v.t["final_cost"])[0]) if done else -1
+            out["heuristic_solution"] = float(self._np(self._v.t["heuristic"])[0])
+        elif self.env_id == "PerishableProductDelivery-v0":  # both keys on every step; the cost is read BEFORE the move (:212-213)
+            out["solution_cost"] = self._last_cost
+            self._last_cost = np.float64(self._np(self._v.t["cost"])[0])
             out["heuristic_solution"] = float(self._np(self._v.t["heuristic"])[0])
         elif done or self.env_id == "LongestPath-v0":
             cost = self._np(self._v.t["cost"])[0]

@@ -27,6 +27,7 @@ _DEFAULTS = {
     "MaxIndependentSet-v0": dict(weighted=True, return_graph_obs=False, is_eval_env=False),
     "MulticastRouting-v0": dict(n_dests=3, weighted=True, max_distance=-1, parenting=4, is_eval_env=False),
     "DistributionCenter-v0": dict(weighted=True, max_distance=1, target_count=-1, return_graph_obs=False, is_eval_env=False, parenting=2),
+    "PerishableProductDelivery-v0": dict(n_products=3, delivery_time=-1, weighted=True, return_graph_obs=False, is_eval_env=False, parenting=-1),
 }
 
 
@@ -58,12 +59,22 @@ def normalize_kwargs(env_id, n_nodes, n_edges=-1, **kwargs):
             kw["target_count"] = n_nodes // 5  # distribution_center.py:42-45
     if env_id == "MulticastRouting-v0" and kw["parenting"] not in [1, 2, 3, 4]:
         raise ValueError("Invalid parenting type")  # multicast_routing.py:34-35
-    if env_id in ("LongestPath-v0", "DensestSubgraph-v0", "MulticastRouting-v0") and n_edges == -1:
+    if env_id == "PerishableProductDelivery-v0":
+        assert kw["parenting"] in [1], "Parenting must be 1!"  # perishable_product_delivery.py:30
+        assert kw["n_products"] <= 5, "Max 5 products!"  # :35
+        # with any other value the reference constructor leaves dt_mn / dt_mx unset and reset() raises AttributeError (:53,92)
+        assert kw["delivery_time"] == -1, "delivery_time must be -1 (the reference only runs with its computed window)"
+    if env_id in ("LongestPath-v0", "DensestSubgraph-v0", "MulticastRouting-v0", "PerishableProductDelivery-v0") and n_edges == -1:
         n_edges = int((n_nodes * (n_nodes - 1) // 2) * 0.30)  # longest_path.py:41-42, multicast_routing.py:53-54
     assert n_edges != -1, f"{env_id} needs n_edges"
     if env_id == "DensestSubgraph-v0" and kw["n_choices"] == -1:
         kw["n_choices"] = float(n_nodes // np.exp(1))  # densest_subgraph.py:38-39
     kw["n_nodes"], kw["n_edges"] = int(n_nodes), int(n_edges)
+    if env_id == "PerishableProductDelivery-v0":  # perishable_product_delivery.py:53-61, in numpy as the reference computes it
+        avg_dist = np.log(n_nodes) / np.log(2 * n_edges / n_nodes)
+        if kw["weighted"]:
+            avg_dist = avg_dist * (0.3 + 1.0) / 2.0
+        kw["_dt_window"] = (float(avg_dist * 0.6), float(avg_dist * 1.4))
     return kw
 
 
@@ -113,10 +124,10 @@ class VectorGraphEnv:
         self.env_index_base = int(env_index_base)
         self.cfg = _lib.GeConfig(
             _lib.ENV_TYPES[env_id], self.num_envs, self.n, self.m, int(bool(kw.get("weighted", False))),
-            int(kw.get("parenting", -1)), int(kw.get("n_dests", kw.get("target_count", 0))), int(bool(kw.get("spatial", False))),
+            int(kw.get("parenting", -1)), int(kw.get("n_dests", kw.get("target_count", kw.get("n_products", 0)))), int(bool(kw.get("spatial", False))),
             int(bool(kw.get("is_eval_env", False))), int(self.autoreset), float(kw.get("n_choices", -1)),
             self.env_index_base, self.seed_stride, int(node_id_base), int(edge_row_stride),
-            float(kw["max_distance"]) if env_id == "DistributionCenter-v0" else 0.0)
+            float(kw["max_distance"]) if env_id == "DistributionCenter-v0" else 0.0, *kw.get("_dt_window", (0.0, 0.0)))
         lay = _lib.GeLayout()
         _lib.check(self._L, self._L.ge_get_layout(C.byref(self.cfg), C.byref(lay)), "ge_get_layout")
         self.layout = lay
@@ -124,7 +135,7 @@ class VectorGraphEnv:
         B, n, E, W, A = self.num_envs, self.n, self.E, self.W, self.A
         AW = (A + 63) // 64
         edge_env = env_id in ("SteinerTree-v0", "MulticastRouting-v0")
-        T = max(2, kw.get("n_dests", 0) + 1) if edge_env else max(2, kw.get("target_count", 0))
+        T = max(2, kw.get("n_dests", 0) + 1) if edge_env else max(2, kw.get("target_count", 0), 2 * kw.get("n_products", 0))
         self.T = T
         dev = self.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)

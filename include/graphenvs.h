@@ -33,7 +33,8 @@ enum {
   GE_DENSEST_SUBGRAPH = 4,    /* densest_subgraph.py DensestSubgraphEnv */
   GE_MAX_INDEPENDENT_SET = 5, /* max_independent_set.py MaxIndependentSet */
   GE_MULTICAST_ROUTING = 6,   /* multicast_routing.py MulticastRoutingEnv */
-  GE_DISTRIBUTION_CENTER = 7  /* distribution_center.py DistributionCenterEnv */
+  GE_DISTRIBUTION_CENTER = 7, /* distribution_center.py DistributionCenterEnv */
+  GE_PERISHABLE_DELIVERY = 8  /* perishable_product_delivery.py PerishableProductDeliveryEnv */
 };
 
 enum {
@@ -54,7 +55,7 @@ typedef struct {
   int32_t n_edges;         /* undirected edge count m (E = 2m directed) */
   int32_t weighted;
   int32_t parenting;
-  int32_t n_dests;         /* SteinerTree, MulticastRouting; DistributionCenter: target_count */
+  int32_t n_dests;         /* SteinerTree, MulticastRouting; DistributionCenter: target_count; PerishableProductDelivery: n_products */
   int32_t spatial;         /* TSP: node coordinates rand()*10, Euclidean float64 edge weights (tsp.py:79-86) */
   int32_t is_eval_env;
   int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset */
@@ -65,6 +66,9 @@ typedef struct {
                               geometry share one PyG slab (ragged batch: variable-size CSR packing) */
   int64_t edge_row_stride; /* elements between the two rows of edge_index; 0 = num_envs * 2 * n_edges */
   double max_distance;     /* DistributionCenter: coverage radius (distribution_center.py:29, default 1) */
+  double dt_min, dt_max;   /* PerishableProductDelivery: delivery-time window.  The reference computes it in its constructor
+                              with numpy (perishable_product_delivery.py:53-61: avg_dist = np.log(n) / np.log(2m/n), times
+                              0.65 when weighted; dt_min = 0.6 avg_dist, dt_max = 1.4 avg_dist); the caller passes the values */
 } ge_config;
 
 /* Sizes (in elements) of every caller-allocated device buffer for a config. */

@@ -57,6 +57,10 @@ CASES = [
     ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), 64, 40),
     ("DistributionCenter-v0", dict(n_nodes=30, n_edges=70, parenting=1, max_distance=0.8, target_count=10), 48, 40),
     ("DistributionCenter-v0", dict(n_nodes=100, n_edges=260, weighted=False, is_eval_env=True), 16, 60),
+    ("PerishableProductDelivery-v0", dict(n_nodes=20, n_edges=50, parenting=1), 32, 150),
+    ("PerishableProductDelivery-v0", dict(n_nodes=8, n_edges=9, parenting=1), 64, 200),  # sparse: placement retries
+    ("PerishableProductDelivery-v0", dict(n_nodes=30, n_edges=90, n_products=5, parenting=1, is_eval_env=True), 16, 600),
+    ("PerishableProductDelivery-v0", dict(n_nodes=100, n_edges=300, n_products=1, weighted=False, parenting=1), 16, 500),
 ]
 
 

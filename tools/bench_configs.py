@@ -14,6 +14,7 @@ CONFIGS = {
     "ds": ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 65536, 100),
     "mc": ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), 65536, 150),
     "dc": ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), 65536, 100),
+    "ppd": ("PerishableProductDelivery-v0", dict(n_nodes=64, n_edges=192, parenting=1), 16384, 300),
 }
 for name in (sys.argv[1:] or ["c3", "c4"]):
     env_id, kw, B, K = CONFIGS[name]
