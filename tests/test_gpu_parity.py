@@ -332,3 +332,88 @@ def test_state_dict_roundtrip_and_unseeded_reset():
     seeds0 = env.t["seed"].clone()
     env.reset()
     assert torch.equal(env.t["seed"], seeds0 + 32) and int(env.t["episode"].sum()) == 0
+
+
+def _random_config(rng):
+    """a random valid constructor call of one of the nine envs (sizes the oracle replays in a moment)"""
+    env_id = str(rng.choice(["ShortestPath-v0", "LongestPath-v0", "SteinerTree-v0", "TSP-v0", "DensestSubgraph-v0", "MaxIndependentSet-v0",
+                         "MulticastRouting-v0", "DistributionCenter-v0", "PerishableProductDelivery-v0"]))
+    n = int(rng.choice([5, 7, 9, 16, 31, 33, 64, 65, 90, 129, 140]))
+    if env_id == "PerishableProductDelivery-v0":
+        n = min(n, 129)
+    ng = n - 1 if env_id == "DensestSubgraph-v0" else n
+    # G(n, m) is sampled by rejection until connected (TSP: also no degree-1 node, no cut through node 0): keep m where
+    # that succeeds within a few attempts -- the reference itself (and the device loop) would spin for ages below it
+    floor_m = int(np.ceil((0.75 if env_id != "TSP-v0" else 1.1) * ng * np.log(ng))) if ng > 9 else ng + 1
+    m = int(min(max(floor_m, round(rng.choice([1.0, 1.3, 2.0, 4.0]) * floor_m)), ng * (ng - 1) // 2))
+    kw = dict(n_nodes=n, n_edges=m)
+    kw["is_eval_env"] = bool(rng.integers(2))
+    if env_id not in ("DensestSubgraph-v0",):
+        kw["weighted"] = bool(rng.integers(4) > 0)
+    if env_id == "LongestPath-v0":
+        kw["parenting"] = int(rng.integers(0, 3))
+    if env_id == "TSP-v0":
+        kw["parenting"] = int(rng.integers(1, 3)); kw["spatial"] = bool(kw["weighted"] and rng.integers(3) == 0)
+    if env_id == "DensestSubgraph-v0":
+        kw["parenting"] = int(rng.integers(0, 2))
+    if env_id == "SteinerTree-v0":
+        kw["n_dests"] = int(rng.integers(1, n))
+    if env_id == "MulticastRouting-v0":
+        kw["n_dests"] = int(rng.integers(1, n)); kw["parenting"] = int(rng.integers(1, 5))
+    if env_id == "DistributionCenter-v0":
+        kw["parenting"] = int(rng.integers(1, 3)); kw["max_distance"] = float(rng.choice([0.5, 1, 1.0, 1.7, 3]))
+        kw["target_count"] = int(rng.integers(0, max(1, n // 2)))
+    if env_id == "PerishableProductDelivery-v0":
+        kw["parenting"] = 1; kw["n_products"] = int(rng.integers(1, min(5, n // 2) + 1))
+    return env_id, kw
+
+
+@pytest.mark.parametrize("chunk", range(6))
+def test_randomized_configs_match_oracle(chunk):
+    """differential test: random constructor arguments of all nine envs, device policy, autoreset, every output compared
+    with the CPU oracle (which is pinned by the reference fixtures)"""
+    import oracle
+    ge = _ge()
+    rng = np.random.default_rng(20260 + chunk)
+    done_cfgs = 0
+    for _ in range(12):
+        env_id, kw = _random_config(rng)
+        B, K, stride, base, s0 = 6, 30, 101, 5, int(rng.integers(0, 2**32))
+        try:
+            env = ge.make_vec(env_id, B, obs_mode="flat", seed_stride=stride, env_index_base=base, **kw)
+        except RuntimeError as e:  # geometry outside what is built (LDS), reported loudly
+            assert "GE_E_TOOBIG" in str(e) or "GE_E_UNSUPPORTED" in str(e) or "fit" in str(e) or "built for" in str(e), (env_id, kw, str(e))
+            continue
+        tag = (env_id, kw, s0)
+        obs, info = env.reset(seed=s0)
+        refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+        seeds = [(s0 + base + i) % 2**32 for i in range(B)]
+        want = np.stack([r.reset(seed=s)[0] for r, s in zip(refs, seeds)])
+        assert np.array_equal(obs.cpu().numpy(), want), tag
+        assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), tag
+        tcount = [0] * B
+        for k in range(K):
+            a = env.sample_random_actions(policy_seed=3).clone()
+            obs, rew, term, trunc, info = env.step(a)
+            a, rew, term = a.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+            fc, fh, solved = info["solution_cost"].cpu().numpy(), info["heuristic_solution"].cpu().numpy(), info["solved"].cpu().numpy()
+            for i, r in enumerate(refs):
+                if a[i] < 0:  # empty mask (e.g. no target to cover): the slot idles
+                    assert not r.mask().any(), tag
+                    continue
+                assert a[i] == oracle.policy_pick(r.mask(), 3, base + i, tcount[i]), tag
+                _, rr, dd, _, inf = r.step(int(a[i]))
+                tcount[i] += 1
+                assert rr == rew[i] and dd == bool(term[i]), (tag, k, i, rr, rew[i])
+                assert int(solved[i]) == (int(inf["solved"]) if "solved" in inf else -1), (tag, k, i)
+                if dd:
+                    assert fc[i] == inf["solution_cost"], (tag, k, i, fc[i], inf["solution_cost"])
+                    if not np.isnan(inf["heuristic_solution"]):
+                        assert fh[i] == inf["heuristic_solution"], (tag, k, i)
+                    seeds[i] = (seeds[i] + stride) % 2**32
+                    r.reset(seed=seeds[i])
+            assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), (tag, k)
+        assert np.array_equal(env.flat_obs().cpu().numpy(), np.stack([r.obs() for r in refs])), tag
+        env.close()
+        done_cfgs += 1
+    assert done_cfgs >= 6
