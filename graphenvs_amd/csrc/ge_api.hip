@@ -33,6 +33,22 @@ extern "C" int ge_abi_version(void) { return GE_ABI_VERSION; }
 
 static const int kMaxLds = 160 * 1024;
 
+// the reset kernel is instantiated per env type (ge_k_reset<ENV>): run `stmt` with ENV bound to the runtime env type
+#define GE_FOR_ENV(env_type, stmt)                                                           \
+  do {                                                                                       \
+    switch (env_type) {                                                                      \
+      case GE_SHORTEST_PATH: { constexpr int ENV = GE_SHORTEST_PATH; stmt; break; }            \
+      case GE_LONGEST_PATH: { constexpr int ENV = GE_LONGEST_PATH; stmt; break; }              \
+      case GE_STEINER_TREE: { constexpr int ENV = GE_STEINER_TREE; stmt; break; }              \
+      case GE_TSP: { constexpr int ENV = GE_TSP; stmt; break; }                                \
+      case GE_DENSEST_SUBGRAPH: { constexpr int ENV = GE_DENSEST_SUBGRAPH; stmt; break; }      \
+      case GE_MAX_INDEPENDENT_SET: { constexpr int ENV = GE_MAX_INDEPENDENT_SET; stmt; break; } \
+      case GE_MULTICAST_ROUTING: { constexpr int ENV = GE_MULTICAST_ROUTING; stmt; break; }    \
+      case GE_DISTRIBUTION_CENTER: { constexpr int ENV = GE_DISTRIBUTION_CENTER; stmt; break; } \
+      default: { constexpr int ENV = GE_PERISHABLE_DELIVERY; stmt; break; }                    \
+    }                                                                                        \
+  } while (0)
+
 static int derive(const ge_config *cfg, GeParams &P) {
   if (!cfg) return fail(GE_E_BADARG, "null config");
   memset(&P, 0, sizeof(P));
@@ -141,7 +157,8 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   e->reset_grid = 256 * per_cu;
   if (e->reset_grid > P.B) e->reset_grid = P.B;
   if (P.lds.total > 64 * 1024) {
-    hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset, P.lds.total);
+    hipError_t hr = hipSuccess;
+    GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset<ENV>, P.lds.total));
     if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
@@ -199,7 +216,7 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
     if (rc != GE_OK) return rc;
   }
   int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  GE_LAUNCH(ge_k_reset, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj);
+  GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_reset<ENV>, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj));
   rc = check_launch("reset kernel");
   if (rc != GE_OK || mode == GE_RESET_INJECT) return rc;
   // the slots just regenerated get the states of their next episode, on the side stream, beside the feature kernel
@@ -370,7 +387,7 @@ extern "C" int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k
 extern "C" int ge_debug_occupancy(ge_engine *e, int *out4) {
   if (!e || !out4) return GE_E_BADARG;
   int a = -1, b = -1, c = -1, d = -1;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ge_k_reset, GE_RESET_THREADS, e->lds_bytes);
+  GE_FOR_ENV(e->P.env_type, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ge_k_reset<ENV>, GE_RESET_THREADS, e->lds_bytes));
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ge_k_features64, GE_F64_THREADS, e->feat_lds);
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ge_k_features, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total);
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, ge_k_step_path64<true>, GE_STEP_BLOCK, step_lds(e));

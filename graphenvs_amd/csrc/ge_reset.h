@@ -593,8 +593,10 @@ GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *m
 
 // The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
 // depend on the topology runs beside the python-stream graph sampling of the first wave.
+template <int ENV>
 GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane) {
-  const int t = P.env_type, n = P.n;
+  constexpr int t = ENV;  // compile-time: every env type gets its own reset kernel, so none pays for the others' registers
+  const int n = P.n;
   if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
   GE_STAMP(20);
   ge_mt_load(c.mt2, P.buf.mt_state + ((int64_t)env * 2 + 1) * GE_MT_N, lane);  // pre-seeded
@@ -639,13 +641,14 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
   GE_STAMP(23);
 }
 
+template <int ENV>
 GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
   // Inside a wave only wave-level hand-offs are used; the two block barriers are the join and the end of the slot.
   const int lane = ge_tid() & (GE_WAVE - 1);
   const int wv = ge_tid() >> 6;
   const int n = P.n, ng = P.ng, W = P.W, m = P.m, E = P.E, F = P.F, T = P.T;
-  const int t = P.env_type;
+  constexpr int t = ENV;
   const bool path_like_t = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   GeRctx c = ge_carve(P);
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
@@ -653,7 +656,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   int ppd_pk[5] = {-1, -1, -1, -1, -1}, ppd_dp[5] = {-1, -1, -1, -1, -1};  // perishable_product_delivery.py:72-73
   double ppd_dt = 0.0;
   if (wv == 1) {
-    if (mode != GE_RESET_INJECT) { ge_numpy_wave(P, c, env, lane); ge_sync(); }
+    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, env, lane); ge_sync(); }
     ge_sync();
     return;
   }
@@ -1212,6 +1215,7 @@ GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int mode) {
   }
 }
 
+template <int ENV>
 GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
@@ -1230,6 +1234,6 @@ GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, c
       ge_sync();  // every thread has its slot before the scratch is reused
     }
     uint32_t seed = (mode == GE_RESET_ALL) ? seeds[env] : ((mode == GE_RESET_QUEUE) ? P.buf.seed[env] : 0u);
-    ge_reset_env(P, env, seed, mode, inj);
+    ge_reset_env<ENV>(P, env, seed, mode, inj);
   }
 }
