@@ -282,7 +282,7 @@ extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) 
   wait_seeded(e, stream);
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0);
-  else GE_LAUNCH(ge_k_step, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_step<ENV>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions));
   return check_launch("step kernel");
 }
 

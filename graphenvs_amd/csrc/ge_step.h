@@ -60,12 +60,14 @@ GE_DEV void ge_reach_thread(const uint64_t *rows, int W, const uint64_t *alive, 
   }
 }
 
+template <int ENV>
 GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
   const int i = i0 + tid;
-  const int n = P.n, W = P.W, F = P.F, A = P.A, AW = P.AW, t = P.env_type;
+  const int n = P.n, W = P.W, F = P.F, A = P.A, AW = P.AW;
+  constexpr int t = ENV;  // one instantiation per env type: the simple envs do not carry the others' registers
   uint64_t *stage = (uint64_t *)ge_dyn_smem();  // [blockDim][W] new node masks (node-action envs)
   const bool edge_mask = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   bool wrote_mask = false;  // this slot's node mask changed and sits in `stage`
