@@ -92,6 +92,11 @@ int64_t oge_rollout(const oge_cfg *cfg, int64_t first_seed, int64_t seed_stride,
                     int32_t n_steps, uint64_t policy_seed, int32_t n_threads,
                     double *out_sum_reward, int64_t *out_episodes, double *out_reset_seconds);
 
+/* test hooks for the own baselines: the independent set (n flags) / the Steiner tree (n*n symmetric flags)
+ * recomputed on the graph of the last reset; both return the heuristic value */
+double oge_debug_greedy_mis(oge_env *e, uint8_t *out_n);
+double oge_debug_steiner_tree(oge_env *e, uint8_t *out_nn);
+
 /* iteration order of a CPython 3.10 set after adding the int pairs (u[i], v[i]) in order (multicast baseline sums a set) */
 int oge_pyset_order(const int32_t *u, const int32_t *v, int count, int32_t *out_u, int32_t *out_v);
 

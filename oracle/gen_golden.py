@@ -60,6 +60,11 @@ CASES = {
     "sp_n512_m1536": ("ShortestPath-v0", dict(n_nodes=512, n_edges=1536), [0]),
     "mis_n200_m600": ("MaxIndependentSet-v0", dict(n_nodes=200, n_edges=600), [0]),
     "ds_n100_m300_p1": ("DensestSubgraph-v0", dict(n_nodes=100, n_edges=300, parenting=1), [0, 1]),
+    # reference values of the heavy baselines (Kou, Christofides, clique-removal MIS), for the bound checks
+    "st_n20_m45_d5_eval": ("SteinerTree-v0", dict(n_nodes=20, n_edges=45, n_dests=5, is_eval_env=True), list(range(8))),
+    "tsp_n10_m20_p1_eval": ("TSP-v0", dict(n_nodes=10, n_edges=20, parenting=1, is_eval_env=True), list(range(8))),
+    "tsp_n12_m30_p2_spatial_eval": ("TSP-v0", dict(n_nodes=12, n_edges=30, parenting=2, spatial=True, is_eval_env=True), list(range(4))),
+    "mis_n12_m20_unweighted_eval": ("MaxIndependentSet-v0", dict(n_nodes=12, n_edges=20, weighted=False, is_eval_env=True), list(range(8))),
     # MulticastRouting (multicast_routing.py)
     "mc_n10_m20_p4": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20), list(range(10))),
     "mc_n10_m20_p3_d2": ("MulticastRouting-v0", dict(n_nodes=10, n_edges=20, n_dests=2, parenting=3), list(range(6))),

@@ -78,6 +78,10 @@ def lib():
         L.oge_rollout.restype = i64
         L.oge_rollout.argtypes = [C.POINTER(OgeCfg), i64, i64, i32, i32, C.c_uint64, i32,
                                   C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
+        L.oge_debug_greedy_mis.restype = dbl
+        L.oge_debug_greedy_mis.argtypes = [vp, vp]
+        L.oge_debug_steiner_tree.restype = dbl
+        L.oge_debug_steiner_tree.argtypes = [vp, vp]
         L.oge_pyset_order.restype = C.c_int
         L.oge_pyset_order.argtypes = [vp, vp, C.c_int, vp, vp]
         L.oge_mt_py_seed.argtypes = [vp, C.c_uint32]
@@ -167,6 +171,14 @@ class OracleEnv:
     @property
     def head(self):
         return self._L.oge_head(self._h)
+
+    def debug_greedy_mis(self):
+        out = np.zeros(self.n, dtype=np.uint8)
+        return self._L.oge_debug_greedy_mis(self._h, out.ctypes.data), out.astype(bool)
+
+    def debug_steiner_tree(self):
+        out = np.zeros((self.n, self.n), dtype=np.uint8)
+        return self._L.oge_debug_steiner_tree(self._h, out.ctypes.data), out.astype(bool)
 
     @property
     def solution_cost(self):

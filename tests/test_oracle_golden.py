@@ -110,3 +110,60 @@ def test_pyset_order_matches_cpython():
         for p in pairs:
             s.add(p)
         assert list(s) == oracle.pyset_order(pairs)
+
+
+# ---- own baselines (validity and bounds instead of bit parity with networkx's Kou / Christofides / clique removal)
+def _nx_graph(env):
+    import networkx as nx
+    G = nx.Graph()
+    G.add_nodes_from(range(env.n))
+    links, w = env.edge_links(), env.edges()[:, 0]
+    for (u, v), d in zip(links, w):
+        G.add_edge(int(u), int(v), delay=float(np.float32(d)))
+    return G
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_own_greedy_mis_is_a_maximal_independent_set_within_the_optimum(seed):
+    import itertools
+    env = oracle.OracleEnv("MaxIndependentSet-v0", n_nodes=12, n_edges=20, weighted=False, is_eval_env=True)
+    env.reset(seed=seed)
+    size, member = env.debug_greedy_mis()
+    G = _nx_graph(env)
+    S = set(np.nonzero(member)[0].tolist())
+    assert size == len(S) == env.heuristic_solution
+    assert not any(G.has_edge(u, v) for u, v in itertools.combinations(S, 2))            # independent
+    assert all(any(G.has_edge(v, u) for u in S) for v in G if v not in S)                 # maximal
+    alpha = max(len(c) for k in range(1, 13) for c in itertools.combinations(range(12), k)
+                if not any(G.has_edge(u, v) for u, v in itertools.combinations(c, 2)))
+    assert len(S) <= alpha and len(S) >= 12 / (max(d for _, d in G.degree()) + 1)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_own_steiner_heuristic_is_a_tree_over_the_terminals_within_twice_the_optimum(seed):
+    import itertools
+    import networkx as nx
+    env = oracle.OracleEnv("SteinerTree-v0", n_nodes=10, n_edges=18, n_dests=3, is_eval_env=True)
+    env.reset(seed=seed)
+    cost, adj = env.debug_steiner_tree()
+    G = _nx_graph(env)
+    terms = [int(t) for t in env.terminals()]
+    T = nx.Graph([(u, v) for u in range(10) for v in range(u + 1, 10) if adj[u, v]])
+    assert all(G.has_edge(u, v) for u, v in T.edges) and nx.is_tree(T) and all(t in T for t in terms)
+    assert all(T.degree(v) > 1 for v in T if v not in terms)                                # no non-terminal leaf
+    assert cost == env.heuristic_solution and abs(cost - sum(G[u][v]["delay"] for u, v in T.edges)) < 1e-6
+    others = [v for v in range(10) if v not in terms]
+    opt = min(nx.minimum_spanning_tree(G.subgraph(terms + list(extra)), weight="delay").size(weight="delay")
+              for k in range(len(others) + 1) for extra in itertools.combinations(others, k)
+              if nx.is_connected(G.subgraph(terms + list(extra))))
+    assert opt - 1e-6 <= cost <= 2 * opt + 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(n_nodes=10, n_edges=20, parenting=1), dict(n_nodes=12, n_edges=30, parenting=2, spatial=True)])
+def test_own_tsp_baseline_is_twice_the_minimum_spanning_tree(kw):
+    import networkx as nx
+    for seed in range(4):
+        env = oracle.OracleEnv("TSP-v0", is_eval_env=True, **kw)
+        env.reset(seed=seed)
+        mst = nx.minimum_spanning_tree(_nx_graph(env), weight="delay").size(weight="delay")
+        assert abs(env.heuristic_solution - 2 * mst) < 1e-4  # edge features are float32 copies of the float64 weights
