@@ -470,6 +470,210 @@ GE_DEV double ge_multicast_baseline(const GeParams &P, const GeRctx &c, int env,
   return total;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Own baselines.  networkx's Kou Steiner tree, Christofides tour and clique-removal independent set depend on
+// dict / set iteration orders deep inside the library; the survey asks validity and bound checks of them, not bit parity.
+// These are this project's deterministic heuristics of the same kind, step for step what oracle/ge_oracle.c does
+// (greedy_mis_size, kou_style_steiner, mst_total), and are compared with the oracle bit for bit.
+
+GE_DEV uint64_t ge_full_word_n(int n, int w) {  // word w of the node set {0..n-1}
+  const int lo = w * 64, hi = lo + 64 < n ? lo + 64 : n;
+  return hi <= lo ? 0ull : (hi - lo == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull));
+}
+
+// total weight of a minimum spanning tree, the picked weights added in ascending order (python sum over Kruskal's edges,
+// steiner_tree.py:80-81).  Weight codes: Prim on the integer codes and a counting sort; spatial TSP: float64 weights.
+GE_DEV double ge_mst_total_wave(const GeParams &P, const GeRctx &c, int env, int lane) {
+  const int n = P.n, W = P.W;
+  uint64_t *intree = c.bits;
+  if (lane < W) intree[lane] = 0ull;
+  double s = 0.0;
+  if (!P.spatial) {
+    for (int v = lane; v < n; v += GE_WAVE) c.dist[v] = (v == 0) ? 0 : 255;
+    if (lane < 16) c.misc[lane] = 0;
+    ge_wave_sync();
+    for (int it = 0; it < n; it++) {
+      uint32_t best = 0xffffffffu;
+      for (int v = lane; v < n; v += GE_WAVE)
+        if (!((intree[v >> 6] >> (v & 63)) & 1ull)) { uint32_t key = ((uint32_t)c.dist[v] << 16) | (uint32_t)v; if (key < best) best = key; }
+      for (int off = 32; off >= 1; off >>= 1) { uint32_t o = ge_shfl_u32(best, lane ^ off); if (o < best) best = o; }
+      int pick = (int)(best & 0xffffu), code = (int)(best >> 16);
+      ge_wave_sync();
+      if (lane == 0) { intree[pick >> 6] |= 1ull << (pick & 63); if (it) c.misc[code & 15]++; }
+      ge_wave_sync();
+      for (int k = c.rowptr[pick] + lane; k < c.rowptr[pick + 1]; k += GE_WAVE) {
+        int u = c.colw[k] >> 4, cd = c.colw[k] & 15;
+        if (!((intree[u >> 6] >> (u & 63)) & 1ull) && cd < c.dist[u]) c.dist[u] = cd;
+      }
+      ge_wave_sync();
+    }
+    for (int code = 3; code <= 10; code++) for (int r = 0; r < c.misc[code]; r++) s += ge_wlut(code);
+    ge_wave_sync();
+    return s;
+  }
+  const double *sw = P.buf.sw64 + (int64_t)env * P.E;  // ascending-neighbour order
+  double *key = c.sigma, *picked = c.delta;
+  for (int v = lane; v < n; v += GE_WAVE) key[v] = (v == 0) ? 0.0 : __builtin_inf();
+  ge_wave_sync();
+  for (int it = 0; it < n; it++) {
+    double bk = __builtin_inf(); int bv = 0x7fffffff;
+    for (int v = lane; v < n; v += GE_WAVE)
+      if (!((intree[v >> 6] >> (v & 63)) & 1ull) && (key[v] < bk || (key[v] == bk && v < bv))) { bk = key[v]; bv = v; }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ok = ge_shfl_f64(bk, lane ^ off); const int ov = ge_shfl_i32(bv, lane ^ off);
+      if (ok < bk || (ok == bk && ov < bv)) { bk = ok; bv = ov; }
+    }
+    const int pick = bv;
+    ge_wave_sync();
+    if (lane == 0) { intree[pick >> 6] |= 1ull << (pick & 63); if (it) picked[it - 1] = bk; }
+    ge_wave_sync();
+    for (int k = c.rowptr[pick] + lane; k < c.rowptr[pick + 1]; k += GE_WAVE) {
+      const int u = c.colw[k] >> 4;
+      const double w = sw[ge_sorted_pos(c, W, pick, u)];
+      if (!((intree[u >> 6] >> (u & 63)) & 1ull) && w < key[u]) key[u] = w;
+    }
+    ge_wave_sync();
+  }
+  if (lane == 0) {  // ascending, then 0 + w0 + w1 + ...
+    for (int a = 1; a < n - 1; a++) { const double w = picked[a]; int b = a - 1; while (b >= 0 && picked[b] > w) { picked[b + 1] = picked[b]; b--; } picked[b + 1] = w; }
+    for (int a = 0; a < n - 1; a++) s += picked[a];
+  }
+  s = ge_shfl_f64(s, 0);
+  ge_wave_sync();
+  return s;
+}
+
+// maximal independent set, min-degree greedy (lowest index on ties); returns its size
+GE_DEV double ge_greedy_mis_wave(const GeParams &P, const GeRctx &c, int lane) {
+  const int n = P.n, W = P.W;
+  uint64_t *alive = c.bits;
+  if (lane < W) alive[lane] = ge_full_word_n(n, lane);
+  ge_wave_sync();
+  int size = 0;
+  for (;;) {
+    uint32_t best = 0xffffffffu;
+    for (int v = lane; v < n; v += GE_WAVE) {
+      if (!((alive[v >> 6] >> (v & 63)) & 1ull)) continue;
+      int d = 0;
+      for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w] & alive[w]);
+      const uint32_t key = ((uint32_t)d << 16) | (uint32_t)v;
+      if (key < best) best = key;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { uint32_t o = ge_shfl_u32(best, lane ^ off); if (o < best) best = o; }
+    if (best == 0xffffffffu) break;
+    const int pick = (int)(best & 0xffffu);
+    size++;
+    ge_wave_sync();
+    if (lane < W) alive[lane] &= ~(c.abits[pick * W + lane] | (((pick >> 6) == lane) ? (1ull << (pick & 63)) : 0ull));
+    ge_wave_sync();
+  }
+  return (double)size;
+}
+
+// 2-approximate Steiner tree in the manner of Kou, Markowsky and Berman (see oracle/ge_oracle.c kou_style_steiner for the
+// statement of every tie-break): Prim over the terminals in the metric closure with one Dijkstra per joining terminal,
+// closure edges expanded along that Dijkstra tree, Prim over the union of the paths, non-terminal leaves pruned, weights
+// added in ascending (u, v).  Bit matrices S (union of paths) and T2 (tree) and the terminal keys live in the `kou` carve.
+GE_DEV double ge_kou_steiner_wave(const GeParams &P, const GeRctx &c, int lane) {
+  const int n = P.n, W = P.W, T = P.n_dests + 1;
+  uint64_t *S = (uint64_t *)(ge_dyn_smem() + P.lds.kou), *T2 = S + n * W;
+  double *key = (double *)(T2 + n * W);
+  int *par = (int *)(key + T), *in = par + T;
+  for (int i = lane; i < 2 * n * W; i += GE_WAVE) S[i] = 0ull;
+  ge_dijkstra_wave(c, n, c.perm[0], lane);
+  for (int j = lane; j < T; j += GE_WAVE) { key[j] = c.sigma[c.perm[j]]; par[j] = 0; in[j] = (j == 0); }
+  ge_wave_sync();
+  for (int it = 1; it < T; it++) {
+    double bk = __builtin_inf(); int bj = 0x7fffffff;
+    for (int k = lane; k < T; k += GE_WAVE) if (!in[k] && (key[k] < bk || (key[k] == bk && k < bj))) { bk = key[k]; bj = k; }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ok = ge_shfl_f64(bk, lane ^ off); const int oj = ge_shfl_i32(bj, lane ^ off);
+      if (ok < bk || (ok == bk && oj < bj)) { bk = ok; bj = oj; }
+    }
+    const int j = bj, tj = c.perm[j];
+    ge_wave_sync();
+    ge_dijkstra_wave(c, n, tj, lane);
+    for (int v = c.perm[par[j]]; v != tj;) {  // walk the Dijkstra tree of t_j from the parent terminal back to t_j
+      int u = 0x7fffffff;
+      for (int k = c.rowptr[v] + lane; k < c.rowptr[v + 1]; k += GE_WAVE) {
+        const int cn = c.colw[k] >> 4;
+        if (c.sigma[cn] + ge_wlut(c.colw[k] & 15) == c.sigma[v] && cn < u) u = cn;
+      }
+      for (int off = 32; off >= 1; off >>= 1) { const int o = ge_shfl_i32(u, lane ^ off); if (o < u) u = o; }
+      if (lane == 0) { S[v * W + (u >> 6)] |= 1ull << (u & 63); S[u * W + (v >> 6)] |= 1ull << (v & 63); }
+      v = u;
+    }
+    ge_wave_sync();
+    if (lane == 0) in[j] = 1;
+    ge_wave_sync();
+    for (int k = lane; k < T; k += GE_WAVE) if (!in[k] && c.sigma[c.perm[k]] < key[k]) { key[k] = c.sigma[c.perm[k]]; par[k] = j; }
+    ge_wave_sync();
+  }
+  // Prim over the union S from the first terminal: keys (w, node), lowest parent on ties
+  double *d2 = c.sigma; int *p2 = c.dist; uint64_t *done = c.bits;
+  for (int v = lane; v < n; v += GE_WAVE) { d2[v] = __builtin_inf(); p2[v] = -1; }
+  if (lane < W) done[lane] = 0ull;
+  ge_wave_sync();
+  if (lane == 0) d2[c.perm[0]] = 0.0;
+  ge_wave_sync();
+  for (;;) {
+    double bk = __builtin_inf(); int bv = 0x7fffffff;
+    for (int v = lane; v < n; v += GE_WAVE)
+      if (!((done[v >> 6] >> (v & 63)) & 1ull) && d2[v] < __builtin_inf() && (d2[v] < bk || (d2[v] == bk && v < bv))) { bk = d2[v]; bv = v; }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ok = ge_shfl_f64(bk, lane ^ off); const int ov = ge_shfl_i32(bv, lane ^ off);
+      if (ov != 0x7fffffff && (bv == 0x7fffffff || ok < bk || (ok == bk && ov < bv))) { bk = ok; bv = ov; }
+    }
+    if (bv == 0x7fffffff) break;
+    const int v = bv;
+    ge_wave_sync();
+    if (lane == 0) {
+      done[v >> 6] |= 1ull << (v & 63);
+      if (p2[v] >= 0) { const int q = p2[v]; T2[v * W + (q >> 6)] |= 1ull << (q & 63); T2[q * W + (v >> 6)] |= 1ull << (v & 63); }
+    }
+    ge_wave_sync();
+    for (int k = c.rowptr[v] + lane; k < c.rowptr[v + 1]; k += GE_WAVE) {
+      const int u = c.colw[k] >> 4;
+      if (!((S[v * W + (u >> 6)] >> (u & 63)) & 1ull) || ((done[u >> 6] >> (u & 63)) & 1ull)) continue;
+      const double w = ge_wlut(c.colw[k] & 15);
+      if (w < d2[u] || (w == d2[u] && v < p2[u])) { d2[u] = w; p2[u] = v; }
+    }
+    ge_wave_sync();
+  }
+  // prune non-terminal leaves (confluent: any order ends in the same tree); terminals as a bit set in c.bits[W..2W)
+  uint64_t *tb = c.bits + W;
+  if (lane < W) { uint64_t b = 0; for (int k = 0; k < T; k++) if ((c.perm[k] >> 6) == lane) b |= 1ull << (c.perm[k] & 63); tb[lane] = b; }
+  ge_wave_sync();
+  for (;;) {
+    uint64_t any = 0;
+    for (int v0 = 0; v0 < n; v0 += GE_WAVE) {
+      const int v = v0 + lane;
+      bool leaf = false; int nb = 0;
+      if (v < n && !((tb[v >> 6] >> (v & 63)) & 1ull)) {
+        int deg = 0;
+        for (int w = 0; w < W; w++) { const uint64_t r = T2[v * W + w]; deg += ge_popc64(r); if (r) nb = w * 64 + ge_ctz64(r); }
+        leaf = deg == 1;
+      }
+      any |= ge_ballot(leaf);
+      ge_wave_sync();
+      if (leaf) { T2[v * W + (nb >> 6)] = 0ull; atomicAnd((unsigned long long *)&T2[nb * W + (v >> 6)], ~(1ull << (v & 63))); }
+      ge_wave_sync();
+    }
+    if (!any) break;
+  }
+  double cost = 0.0;
+  if (lane == 0)
+    for (int u = 0; u < n; u++)
+      for (int w = 0; w < W; w++)
+        for (uint64_t r = T2[u * W + w]; r; r &= r - 1) {
+          const int v = w * 64 + ge_ctz64(r);
+          if (v > u) cost += ge_wlut(c.wsort[ge_sorted_pos(c, W, u, v)]);
+        }
+  cost = ge_shfl_f64(cost, 0);
+  ge_wave_sync();
+  return cost;
+}
+
 // one 32-bit numpy draw, wave-uniform (every lane reads the same word)
 GE_DEV uint32_t ge_np_next(uint32_t *mt, int &nppos, int lane) {
   if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
@@ -923,37 +1127,15 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       heuristic = (t == GE_LONGEST_PATH) ? -d : d;
       ge_wave_sync();
     } else if (t == GE_STEINER_TREE && P.n_dests == n - 1) {
-      // steiner_tree.py:80-81 MST total: Prim on integer codes, summed in ascending order
-      for (int v = lane; v < n; v += GE_WAVE) c.dist[v] = (v == 0) ? 0 : 255;
-      if (lane < 16) c.misc[lane] = 0;
-      uint64_t *intree = c.bits;
-      if (lane < W) intree[lane] = 0ull;
-      ge_wave_sync();
-      for (int it = 0; it < n; it++) {
-        uint32_t best = 0xffffffffu;
-        for (int v = lane; v < n; v += GE_WAVE)
-          if (!((intree[v >> 6] >> (v & 63)) & 1ull)) { uint32_t key = ((uint32_t)c.dist[v] << 16) | (uint32_t)v; if (key < best) best = key; }
-        for (int off = 32; off >= 1; off >>= 1) { uint32_t o = ge_shfl_u32(best, lane ^ off); if (o < best) best = o; }
-        int pick = (int)(best & 0xffffu), code = (int)(best >> 16);
-        ge_wave_sync();
-        if (lane == 0) { intree[pick >> 6] |= 1ull << (pick & 63); if (it) c.misc[code & 15]++; }
-        ge_wave_sync();
-        for (int k = c.rowptr[pick] + lane; k < c.rowptr[pick + 1]; k += GE_WAVE) {
-          int u = c.colw[k] >> 4, cd = c.colw[k] & 15;
-          if (!((intree[u >> 6] >> (u & 63)) & 1ull) && cd < c.dist[u]) c.dist[u] = cd;
-        }
-        ge_wave_sync();
-      }
-      double s = 0.0;
-      for (int code = 3; code <= 10; code++) for (int r = 0; r < c.misc[code]; r++) s += ge_wlut(code);
-      heuristic = s;
-      ge_wave_sync();
+      heuristic = ge_mst_total_wave(P, c, env, lane);  // steiner_tree.py:80-81
     } else if (t == GE_DENSEST_SUBGRAPH) heuristic = -1.0;             // densest_subgraph.py:85-88
-    else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : kNaN;  // greedy MIS not built
+    else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : ge_greedy_mis_wave(P, c, lane);  // own greedy in place of clique removal
+    else if (t == GE_TSP) { const double mst = ge_mst_total_wave(P, c, env, lane); heuristic = mst + mst; }  // own double-tree walk in place of Christofides
+    else if (t == GE_STEINER_TREE) heuristic = ge_kou_steiner_wave(P, c, lane);  // own 2-approximation in place of networkx's Kou
     else if (t == GE_MULTICAST_ROUTING) heuristic = 0.0;                 // computed below, after the delay bound
     else if (t == GE_DISTRIBUTION_CENTER) heuristic = -1.0;              // distribution_center.py:91
     else if (t == GE_PERISHABLE_DELIVERY) heuristic = 0.0;               // computed below
-    else heuristic = kNaN;                                              // Kou / Christofides not built
+    else heuristic = kNaN;
   }
 
   // ------------------------------------------------------------------ multicast: delay bound (multicast_routing.py:101-106)

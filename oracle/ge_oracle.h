@@ -7,7 +7,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  * The product (graphenvs_amd/, libgraphenvs_hip.so) never links, imports or calls it.
  *
- * Parity status: PINNED -- oracle/gen_golden.py runs the real reference in the build
+ * Parity status: PINNED (except the three own baselines, see ge_oracle.c "own baselines": bound-checked) -- oracle/gen_golden.py runs the real reference in the build
  * container and tests/test_oracle_golden.py checks this file against those fixtures
  * (tests/golden/*.npz) and against the known answers of SURVEY.md section 10.
  */

@@ -211,6 +211,7 @@ GE_DEV int ge_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
 template <class T> GE_DEV T atomicAdd(T *p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> GE_DEV T atomicOr(T *p, T v) { T o = *p; *p = (T)(o | v); return o; }
+template <class T> GE_DEV T atomicAnd(T *p, T v) { T o = *p; *p = (T)(o & v); return o; }
 template <class T> GE_DEV T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 
 #define GE_LAUNCH(kernel, grid, block, smem, stream, ...) \

@@ -49,6 +49,12 @@ CASES = [
     ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 64, 60),
     ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=60, parenting=0, is_eval_env=True), 64, 40),
     ("MaxIndependentSet-v0", dict(n_nodes=70, n_edges=200), 64, 150),
+    # own baselines: engine == oracle exactly; oracle vs reference by bounds (test_oracle_golden.py)
+    ("SteinerTree-v0", dict(n_nodes=40, n_edges=100, n_dests=5, is_eval_env=True), 32, 60),
+    ("SteinerTree-v0", dict(n_nodes=70, n_edges=200, n_dests=30, is_eval_env=True), 16, 80),
+    ("TSP-v0", dict(n_nodes=16, n_edges=60, parenting=1, is_eval_env=True), 32, 40),
+    ("TSP-v0", dict(n_nodes=70, n_edges=400, parenting=1, spatial=True, is_eval_env=True), 16, 80),
+    ("MaxIndependentSet-v0", dict(n_nodes=130, n_edges=500, weighted=False, is_eval_env=True), 16, 140),
     ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), 64, 80),
     ("MulticastRouting-v0", dict(n_nodes=40, n_edges=100, n_dests=4, parenting=2), 48, 60),
     ("MulticastRouting-v0", dict(n_nodes=30, n_edges=70, n_dests=6, parenting=3, is_eval_env=True), 48, 60),
