@@ -60,6 +60,10 @@ static int derive(const ge_config *cfg, GeParams &P) {
   const double max_edges = (double)ng * (ng - 1) / 2.0;
   if (m < ng - 1) return fail(GE_E_BADARG, "n_edges < nodes-1: no connected graph exists (the reference would loop forever)");
   if (m > max_edges) return fail(GE_E_BADARG, "n_edges exceeds the complete graph");
+  // G(n, m) is sampled by rejection until it is connected.  P(connected) ~ exp(-n e^(-2m/n)) (Erdos-Renyi): below 1e-7 the
+  // reference would spin for hours per reset and a device loop of that length is a hung GPU -- refuse it loudly instead.
+  if (m < max_edges && (double)ng * exp(-2.0 * (double)m / (double)ng) > 16.2)
+    return fail(GE_E_UNSUPPORTED, "n_edges is so small for n_nodes that a random G(n, m) is connected with probability < 1e-7: the reference's rejection loop would not terminate in practice");
   // constructor asserts of the reference
   if (t == GE_SHORTEST_PATH && cfg->parenting != -1) return fail(GE_E_BADARG, "Parenting is not available for shortest path (shortest_path.py:26)");
   if (t == GE_STEINER_TREE && cfg->parenting != -1) return fail(GE_E_BADARG, "Parenting not available for this environment (steiner_tree.py:29)");

@@ -92,3 +92,13 @@ def test_codec_roundtrip_and_env_info():
     assert g.x.shape == (bs * n, 7) and g.edge_index.shape == (2, bs * 2 * m)
     assert torch.equal(g.edge_index[:, 2 * m:4 * m], torch.from_numpy(links[1]).T + n)  # utils.py:27 offset by i*n
     assert torch.equal(g.ptr, torch.arange(bs + 1) * n)
+
+
+def test_hopeless_rejection_sampling_is_refused_without_a_gpu():
+    """a G(n, m) that is connected with probability < 1e-7 would spin the reset kernel for ever (the reference too)"""
+    L = _lib.load()
+    cfg = _lib.GeConfig(0, 4, 140, 147, 1, -1, 0, 0, 0, 1, -1.0, 0, 4, 0, 0, 0.0, 0.0, 0.0)
+    lay = _lib.GeLayout()
+    assert L.ge_get_layout(C.byref(cfg), C.byref(lay)) == -2 and b"probability" in L.ge_last_error()
+    cfg = _lib.GeConfig(0, 4, 64, 70, 1, -1, 0, 0, 0, 1, -1.0, 0, 4, 0, 0, 0.0, 0.0, 0.0)  # ~1 400 attempts on average: fine
+    assert L.ge_get_layout(C.byref(cfg), C.byref(lay)) == 0
