@@ -97,7 +97,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (t == GE_PERISHABLE_DELIVERY) { P.T = 2 * cfg->n_dests; P.dt_min = cfg->dt_min; P.dt_max = cfg->dt_max; }
   P.weighted = cfg->weighted ? 1 : 0; P.parenting = cfg->parenting; P.n_dests = cfg->n_dests;
   P.spatial = (t == GE_TSP && cfg->spatial) ? 1 : 0;
-  P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset ? 1 : 0;
+  P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset == 2 ? 2 : (cfg->autoreset ? 1 : 0);
   P.complete = (m >= max_edges) ? 1 : 0;
   P.n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;  // densest_subgraph.py:38-39
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
@@ -260,6 +260,9 @@ extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
   if (!e || !seeds) return fail(GE_E_BADARG, "null argument");
  
   GeInject none = {nullptr, nullptr, nullptr, nullptr};
+  // next-step mode consumes the finished-slot queue at the start of ge_step: a full reset leaves it empty
+  if (e->P.autoreset == 2 && hipMemsetAsync(e->P.buf.reset_count, 0, sizeof(int32_t) * (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK), (hipStream_t)stream) != hipSuccess)
+    return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
   return launch_reset(e, seeds, GE_RESET_ALL, none, stream);
 }
 
@@ -313,6 +316,10 @@ extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
 }
 
 extern "C" int ge_step(ge_engine *e, const int64_t *actions, void *stream) {
+  if (e && e->P.autoreset == 2) {  // next-step mode: the slots that finished in the previous step are regenerated first
+    int rc = ge_reset_pending(e, stream);
+    return rc == GE_OK ? ge_step_only(e, actions, stream) : rc;
+  }
   int rc = ge_step_only(e, actions, stream);
   if (rc != GE_OK) return rc;
   return ge_reset_pending(e, stream);
@@ -338,8 +345,10 @@ extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *ac
 extern "C" int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *scratch, void *stream) {
   if (!e || !scratch) return fail(GE_E_BADARG, "null argument");
   for (int s = 0; s < n_steps; s++) {
-    int rc = sample_and_step(e, policy_seed, scratch, stream);
-    if (rc == GE_OK) rc = ge_reset_pending(e, stream);
+    int rc = GE_OK;
+    if (e->P.autoreset == 2) rc = ge_reset_pending(e, stream);
+    if (rc == GE_OK) rc = sample_and_step(e, policy_seed, scratch, stream);
+    if (rc == GE_OK && e->P.autoreset != 2) rc = ge_reset_pending(e, stream);
     if (rc != GE_OK) return rc;
   }
   return GE_OK;
@@ -353,12 +362,13 @@ extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_st
   hipStream_t st = (hipStream_t)stream;
   for (int s = 0; s < n_steps; s++) {
     int rc = GE_OK;
+    if (e->P.autoreset == 2) rc = ge_reset_pending(e, stream);  // next-step mode: counted with nothing (the timed split is for same-step runs)
     (void)hipEventRecord(e->ev[0], st);
-    if (!path64(e)) rc = ge_sample_actions(e, policy_seed, scratch, stream);
+    if (rc == GE_OK && !path64(e)) rc = ge_sample_actions(e, policy_seed, scratch, stream);
     (void)hipEventRecord(e->ev[1], st);
     if (rc == GE_OK) rc = path64(e) ? sample_and_step(e, policy_seed, scratch, stream) : ge_step_only(e, scratch, stream);
     (void)hipEventRecord(e->ev[2], st);
-    if (rc == GE_OK) rc = ge_reset_pending(e, stream);
+    if (rc == GE_OK && e->P.autoreset != 2) rc = ge_reset_pending(e, stream);
     (void)hipEventRecord(e->ev[3], st);
     if (rc != GE_OK) return rc;
     if (hipEventSynchronize(e->ev[3]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventSynchronize failed");

@@ -1318,7 +1318,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   if (lane == 0) {
     G.head[env] = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? -1 : src;
     G.cost[env] = 0.0; G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
-    G.status[env] = 0; G.heuristic[env] = heuristic;
+    G.status[env] = (mode == GE_RESET_QUEUE && P.autoreset == 2) ? 3 : 0;  // 3: regenerated at the start of this ge_step (next-step mode)
+    G.heuristic[env] = heuristic;
     if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
   }
   ge_sync();

@@ -82,7 +82,9 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
     bool cost_hidden = false;  // multicast: info['solution_cost'] stays -1 unless the episode is solved
     bool cost_lagged = false; double cost_before = 0.0;  // perishable delivery: info['solution_cost'] is read before the move
     if (st != 0 || a64 == -1) {
-      // frozen slot (finished, autoreset off) or explicit no-op: nothing moves
+      // frozen slot (finished, autoreset off), a slot regenerated at the start of this step (next-step autoreset: its
+      // action is ignored) or an explicit no-op: nothing moves
+      if (st == 3) G.status[i] = 0;
     } else {
       bool in_range = a64 >= 0 && a64 < (int64_t)A;
       int a = in_range ? (int)a64 : 0;
@@ -421,7 +423,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
           G.seed[i] = G.seed[i] + (uint32_t)P.seed_stride;
           G.episode[i] = G.episode[i] + 1;
           G.status[i] = 2;
-          wrote_mask = false;  // the reset kernel rewrites the whole slot
+          if (P.autoreset == 1) wrote_mask = false;  // same-step: the reset kernel rewrites the whole slot right away
         } else {
           G.status[i] = 1;
         }
@@ -560,7 +562,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
     }
     const bool fin = acted && done;
     want_reset = fin && P.autoreset;
-    wrote_mask = moved && !open_mask && !want_reset;
+    wrote_mask = moved && !open_mask && !(want_reset && P.autoreset == 1);  // same-step: the reset kernel rewrites the slot right away
     stage[tid] = nm;
 
     // ---- phase C: stores only
@@ -586,6 +588,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
       }
     }
     if (wrote_mask && GE_ON(16)) G.mask_bits[i] = nm;
+    if (st == 3) G.status[i] = 0;  // regenerated at the start of this step (next-step autoreset): its action was ignored
     if (fin) {
       G.final_cost[i] = cost;
       G.final_heur[i] = heur0;

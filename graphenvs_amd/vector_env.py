@@ -109,6 +109,11 @@ class VectorGraphEnv:
         self.device = torch.device(device)
         self.obs_mode = obs_mode
         self.strict = strict
+        # True / "same_step": a finished slot is regenerated inside the same step(); "next_step" (gymnasium's default mode): the
+        # step that ends an episode returns its final observation and the NEXT step() regenerates the slot, ignoring its action;
+        # False: finished slots freeze until reset()
+        assert autoreset in (True, False, "same_step", "next_step"), autoreset
+        self.autoreset_mode = 2 if autoreset == "next_step" else int(bool(autoreset))
         self.autoreset = bool(autoreset)
         if _library is None:
             if self.device.type != "cuda":
@@ -125,7 +130,7 @@ class VectorGraphEnv:
         self.cfg = _lib.GeConfig(
             _lib.ENV_TYPES[env_id], self.num_envs, self.n, self.m, int(bool(kw.get("weighted", False))),
             int(kw.get("parenting", -1)), int(kw.get("n_dests", kw.get("target_count", kw.get("n_products", 0)))), int(bool(kw.get("spatial", False))),
-            int(bool(kw.get("is_eval_env", False))), int(self.autoreset), float(kw.get("n_choices", -1)),
+            int(bool(kw.get("is_eval_env", False))), self.autoreset_mode, float(kw.get("n_choices", -1)),
             self.env_index_base, self.seed_stride, int(node_id_base), int(edge_row_stride),
             float(kw["max_distance"]) if env_id == "DistributionCenter-v0" else 0.0, *kw.get("_dt_window", (0.0, 0.0)))
         lay = _lib.GeLayout()

@@ -58,7 +58,10 @@ typedef struct {
   int32_t n_dests;         /* SteinerTree, MulticastRouting; DistributionCenter: target_count; PerishableProductDelivery: n_products */
   int32_t spatial;         /* TSP: node coordinates rand()*10, Euclidean float64 edge weights (tsp.py:79-86) */
   int32_t is_eval_env;
-  int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset */
+  int32_t autoreset;       /* 0: finished slots freeze until ge_reset; 1: same-step autoreset (the step that ends an episode returns
+                              the new episode's observation and mask beside the old episode's reward / final_*); 2: next-step
+                              autoreset (gymnasium's default: that step returns the final observation, the NEXT ge_step
+                              regenerates the slot, ignores its action and returns reward 0, terminated 0) */
   double n_choices;        /* DensestSubgraph; < 0 -> floor(n / e) as densest_subgraph.py:38-39 */
   int64_t env_index_base;  /* global index of slot 0 (multi-GPU shard of the batch dimension) */
   int64_t seed_stride;     /* episode k of a slot seeded s0 runs reset(seed=(s0 + k*seed_stride) mod 2^32) */
@@ -108,7 +111,7 @@ typedef struct {
   uint32_t *seed;       /* [B]  seed of the slot's current episode                           */
   int64_t *episode;     /* [B]  episode index k of the slot                                  */
   int64_t *tstep;       /* [B]  transitions executed by the slot since creation              */
-  uint8_t *status;      /* [B]  0 = running, 1 = finished (autoreset off), 2 = needs reset   */
+  uint8_t *status;      /* [B]  0 = running, 1 = finished (autoreset off), 2 = needs reset, 3 = regenerated in this ge_step (next-step mode) */
   double *heuristic;    /* [B]  heuristic_solution of the current episode (is_eval_env)      */
   uint32_t *mt_state;   /* [B, 2, 624] MT19937 states (python stream, numpy stream) already seeded for the slot's NEXT
                                  reset: seeded one lane per slot by a helper kernel on the engine's side stream */

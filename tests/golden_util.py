@@ -114,3 +114,37 @@ def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True
                         assert h == int(h) and 1 <= h <= n and 1 <= ref_h <= n, what
                         stats["mis_ours_ge_ref"] = stats.get("mis_ours_ge_ref", 0) + int(h >= ref_h)
     return stats
+
+
+def check_next_step_autoreset(ge, oracle, env_id, kw, B, K, device, lib=None):
+    """next-step autoreset (gymnasium's default mode): the step that ends an episode returns the final observation and mask,
+    the following step() regenerates the slot with its next seed, ignores its action and returns reward 0, terminated False"""
+    stride = 100
+    extra = dict(_library=lib) if lib is not None else {}
+    env = ge.VectorGraphEnv(env_id, B, device=device, obs_mode="flat", autoreset="next_step", seed_stride=stride, **extra, **kw)
+    env.reset(seed=7)
+    refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+    seeds = [7 + i for i in range(B)]
+    for r, s in zip(refs, seeds):
+        r.reset(seed=s)
+    pending, tcount, resets = [False] * B, [0] * B, 0
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=3).clone()
+        obs, rew, term, trunc, info = env.step(a)
+        a, rew, term = a.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+        for i, r in enumerate(refs):
+            if pending[i]:
+                seeds[i] = (seeds[i] + stride) % 2**32
+                r.reset(seed=seeds[i]); pending[i] = False; resets += 1
+                assert rew[i] == 0 and not term[i], (env_id, k, i)
+            else:
+                assert a[i] == oracle.policy_pick(r.mask(), 3, i, tcount[i]), (env_id, k, i)
+                _, rr, dd, _, inf = r.step(int(a[i])); tcount[i] += 1
+                assert rr == rew[i] and dd == bool(term[i]), (env_id, k, i)
+                if dd:
+                    pending[i] = True
+                    assert float(info["solution_cost"][i]) == inf["solution_cost"]
+        assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), (env_id, k)
+        assert np.array_equal(env.flat_obs().cpu().numpy(), np.stack([r.obs() for r in refs])), (env_id, k)
+    assert resets > 0
+    env.close()

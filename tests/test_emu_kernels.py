@@ -130,3 +130,9 @@ def test_emulated_inject_state_then_step(emu, env_id, kw):
     import oracle
     from inject_check import check_inject
     check_inject(ge, oracle, "cpu", env_id, kw, library=emu)
+
+
+def test_emulated_next_step_autoreset(emu):
+    import oracle
+    gu.check_next_step_autoreset(ge, oracle, "ShortestPath-v0", dict(n_nodes=10, n_edges=20), 5, 40, "cpu", lib=emu)
+    gu.check_next_step_autoreset(ge, oracle, "SteinerTree-v0", dict(n_nodes=12, n_edges=26, n_dests=3), 4, 40, "cpu", lib=emu)

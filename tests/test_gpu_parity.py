@@ -423,3 +423,14 @@ def test_randomized_configs_match_oracle(chunk):
         env.close()
         done_cfgs += 1
     assert done_cfgs >= 6
+
+
+@pytest.mark.parametrize("env_id,kw", [("ShortestPath-v0", dict(n_nodes=64, n_edges=192)),
+                                       ("LongestPath-v0", dict(n_nodes=24, n_edges=50, parenting=2)),
+                                       ("TSP-v0", dict(n_nodes=14, n_edges=40, parenting=2)),
+                                       ("MulticastRouting-v0", dict(n_nodes=30, n_edges=70, n_dests=4)),
+                                       ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=60, parenting=1)),
+                                       ("DistributionCenter-v0", dict(n_nodes=70, n_edges=200))])
+def test_next_step_autoreset_matches_oracle(env_id, kw):
+    import oracle
+    gu.check_next_step_autoreset(_ge(), oracle, env_id, kw, 48, 80, "cuda")
