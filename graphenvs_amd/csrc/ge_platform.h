@@ -49,6 +49,9 @@ GE_DEV uint64_t ge_shfl_u64(uint64_t v, int src) {
 GE_DEV double ge_shfl_f64(double v, int src) { return __longlong_as_double((long long)ge_shfl_u64((uint64_t)__double_as_longlong(v), src)); }
 // value of lane `idx` where idx is wave-uniform: v_readlane_b32, no LDS
 GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, idx); }
+// v with lane `idx` replaced by `val` (idx and val wave-uniform): a compare against the lane id and a select (v_writelane_b32
+// would need the lane index in M0 beside the scalar value: one constant-bus operand only)
+GE_DEV uint32_t ge_writelane_u32(uint32_t v, uint32_t val, int idx) { return ((int)(threadIdx.x & 63u) == idx) ? val : v; }
 // value known to be the same in every lane: keep it (and what is computed from it) on the scalar unit
 GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 GE_DEV int ge_popc64(uint64_t v) { return __popcll(v); }

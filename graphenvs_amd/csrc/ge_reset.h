@@ -112,8 +112,7 @@ GE_DEV int ge_wave_incl_scan(int x, int lane) {
 }
 
 GE_DEV uint32_t ge_mask_below(uint32_t v) {  // smallest 2^k - 1 >= v
-  v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
-  return v;
+  return v ? (0xffffffffu >> ge_clz32(v)) : 0u;
 }
 
 struct GeRctx {
@@ -280,59 +279,68 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
   ge_wave_sync();  // rounds only read the state and add into their sink: one ordering point at the end
 }
 
-// np.random.choice(n, k, replace=False) = permutation(n)[:k]: full Fisher-Yates, one lane; result in c.perm
-// legacy numpy permutation(pn) into c.perm (np.random.choice(pn, k, replace=False) is its first k entries)
-GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane, int pn) {
+// first `need` entries of legacy numpy permutation(pn) into c.perm (np.random.choice(pn, k, replace=False) is its first k entries)
+GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane, int pn, int need) {
+  // Fisher-Yates from the top: for i = pn-1 .. 1: j_i = interval(i) (masked rejection), swap(a[i], a[j_i]).  Only the first
+  // `need` entries of the result are used, and the content of a final position can be traced BACKWARDS through the swaps
+  // (last swap first): pos = p; for i = 1 .. pn-1: pos == i ? j_i : (pos == j_i ? i : pos) ends at the element that lands
+  // in p.  So the only serial part is the acceptance scan that finds the j_i (a few scalar operations per raw draw); the
+  // trace runs one lane per wanted position.
   const int n = pn;
-  if (n <= 4 * GE_WAVE) {
-    // the permutation lives in (up to four) registers per lane: element e sits in lane e % 64, register e / 64.  A swap is
-    // two v_readlane + selects, and the draws of a round are tempered 64 at a time, so the serial Fisher-Yates chain
-    // never waits on LDS
-    uint32_t pv0 = (uint32_t)lane, pv1 = (uint32_t)lane + 64u, pv2 = (uint32_t)lane + 128u, pv3 = (uint32_t)lane + 192u;
-    int i = n - 1;
+  int i = n - 1;
+  if (n <= 4 * GE_WAVE && need <= GE_WAVE) {
+    // the j's stay in (up to four) registers, j_i in lane i % 64 of register i / 64: v_writelane in the scan, v_readlane in the
+    // trace, no LDS anywhere in the two serial loops
+    uint32_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
     while (i >= 1) {
       if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
       const int avail = (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
       const uint32_t dr = lane < avail ? ge_temper(mt[nppos + lane]) : 0u;
       int k = 0;
-      while (i >= 1 && k < avail) {  // wave-uniform loop
+      while (i >= 1 && k < avail) {  // wave-uniform
         const uint32_t j = ge_readlane_u32(dr, k) & ge_mask_below((uint32_t)i);
         k++;
         if (j > (uint32_t)i) continue;
-        const int si = i >> 6, sj = (int)j >> 6;  // wave-uniform register selectors
-        const uint32_t vi = ge_readlane_u32(si == 0 ? pv0 : si == 1 ? pv1 : si == 2 ? pv2 : pv3, i & 63);
-        const uint32_t vj = ge_readlane_u32(sj == 0 ? pv0 : sj == 1 ? pv1 : sj == 2 ? pv2 : pv3, (int)j & 63);
-        if (lane == (i & 63)) { if (si == 0) pv0 = vj; else if (si == 1) pv1 = vj; else if (si == 2) pv2 = vj; else pv3 = vj; }
-        if (lane == ((int)j & 63)) { if (sj == 0) pv0 = vi; else if (sj == 1) pv1 = vi; else if (sj == 2) pv2 = vi; else pv3 = vi; }
+        const int r = i >> 6;
+        if (r == 0) j0 = ge_writelane_u32(j0, j, i & 63); else if (r == 1) j1 = ge_writelane_u32(j1, j, i & 63);
+        else if (r == 2) j2 = ge_writelane_u32(j2, j, i & 63); else j3 = ge_writelane_u32(j3, j, i & 63);
         i--;
       }
       nppos += k;
     }
-    if (lane < n) c.perm[lane] = (int)pv0;
-    if (lane + 64 < n) c.perm[lane + 64] = (int)pv1;
-    if (lane + 128 < n) c.perm[lane + 128] = (int)pv2;
-    if (lane + 192 < n) c.perm[lane + 192] = (int)pv3;
+    int pos = lane;
+    for (int q = 1; q < n; q++) {
+      const int r = q >> 6;
+      const int j = (int)ge_readlane_u32(r == 0 ? j0 : r == 1 ? j1 : r == 2 ? j2 : j3, q & 63);
+      pos = (pos == q) ? j : ((pos == j) ? q : pos);
+    }
+    if (lane < need && lane < n) c.perm[lane] = pos;
     ge_wave_sync();
     return;
   }
-  for (int v = lane; v < n; v += GE_WAVE) c.perm[v] = v;
-  ge_wave_sync();
-  int i = n - 1;
-  for (;;) {
+  while (i >= 1) {
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
-    if (lane == 0) {
-      while (i >= 1 && nppos < GE_MT_N) {
-        uint32_t j = ge_temper(mt[nppos++]) & ge_mask_below((uint32_t)i);
-        if (j > (uint32_t)i) continue;
-        int tv = c.perm[i]; c.perm[i] = c.perm[(int)j]; c.perm[(int)j] = tv;
-        i--;
-      }
+    const int avail = (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+    const uint32_t dr = lane < avail ? ge_temper(mt[nppos + lane]) : 0u;
+    int k = 0;
+    while (i >= 1 && k < avail) {  // wave-uniform
+      const uint32_t j = ge_readlane_u32(dr, k) & ge_mask_below((uint32_t)i);
+      k++;
+      if (j > (uint32_t)i) continue;
+      if (lane == 0) c.perm[i] = (int)j;
+      i--;
     }
-    nppos = ge_shfl_i32(nppos, 0);
-    int ib = ge_shfl_i32(i, 0);
-    ge_wave_sync();
-    if (ib < 1) break;
+    nppos += k;
   }
+  ge_wave_sync();
+  for (int p0 = 0; p0 < need; p0 += GE_WAVE) {
+    int pos = p0 + lane;
+    for (int q = 1; q < n; q++) { const int j = c.perm[q]; pos = (pos == q) ? j : ((pos == j) ? q : pos); }
+    if (p0 + lane < need && p0 + lane < n) c.dist[p0 + lane] = pos;  // perm[] still holds the j's the next chunk reads
+  }
+  ge_wave_sync();
+  for (int p = lane; p < need && p < n; p += GE_WAVE) c.perm[p] = c.dist[p];
+  ge_wave_sync();
 }
 
 // [nx] dijkstra from `src` to every node: least fixpoint of d[u] = min_v fl(d[v] + w(v,u)) (float addition is monotone, so
@@ -775,7 +783,7 @@ GE_DEV bool ge_ppd_place(const GeParams &P, const GeRctx &c, double *D, double r
 // MulticastRouting tail of the numpy stream (multicast_routing.py:98,106): dests = arange(1, n)[permutation(n - 1)[:k]],
 // then ONE rand() for max_distance.  Leaves perm[0] = 0 (the source), perm[1..k] = dests and the rand in misc[0..1].
 GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
-  ge_np_terminals(P, c, mt, nppos, lane, P.n - 1);
+  ge_np_terminals(P, c, mt, nppos, lane, P.n - 1, P.n_dests);
   const int k = P.n_dests;
   for (int base = ((k - 1) / GE_WAVE) * GE_WAVE; base >= 0; base -= GE_WAVE) {  // shift up by one slot, +1 on the values
     const int idx = base + lane;
@@ -841,7 +849,7 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
     return;
   }
   if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
-  else if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane, n);
+  else if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane, n, P.T);
   GE_STAMP(23);
 }
 
@@ -1088,7 +1096,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 2);
       if (t == GE_DISTRIBUTION_CENTER) ge_np_draws(P, c, c.mt2, nppos, n, lane, 3);
       if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
-      else ge_np_terminals(P, c, c.mt2, nppos, lane, n);
+      else ge_np_terminals(P, c, c.mt2, nppos, lane, n, P.T);
     }
     ge_wave_sync();
     for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order

@@ -187,6 +187,7 @@ GE_DEV uint64_t ge_shfl_u64(uint64_t v, int src) {
 GE_DEV int ge_shfl_i32(int v, int src) { return (int)(int64_t)ge_shfl_u64((uint64_t)(int64_t)v, src); }
 GE_DEV uint32_t ge_shfl_u32(uint32_t v, int src) { return (uint32_t)ge_shfl_u64(v, src); }
 GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx) { return ge_shfl_u32(v, idx); }
+GE_DEV uint32_t ge_writelane_u32(uint32_t v, uint32_t val, int idx) { return ((ge_tid() & 63) == idx) ? val : v; }
 GE_DEV double ge_shfl_f64(double v, int src) { uint64_t u; memcpy(&u, &v, 8); u = ge_shfl_u64(u, src); memcpy(&v, &u, 8); return v; }
 
 GE_DEV uint32_t ge_quad_xchg(uint32_t v, int xr) {
