@@ -7,6 +7,9 @@
 #define GE_WAVE 64
 #define GE_MT_N 624
 #define GE_MT_M 397
+#ifndef GE_DC_LANES
+#define GE_DC_LANES 32  // DistributionCenter, n <= 64: sources searched at a time (lanes), 64 / GE_DC_LANES passes; sizes the LDS columns
+#endif
 #ifndef GE_STEP_BLOCK
 #define GE_STEP_BLOCK 256
 #endif
@@ -33,6 +36,7 @@ struct GeLds {
   int bits;     // u64[6][W] frontier / visited / next / removed-or-targets / prune / removed (first mask)
   int misc;     // i32[16]
   int fw;       // f64[n*n]  PerishableProductDelivery: Floyd-Warshall matrix (else absent)
+  int dcs;      // DistributionCenter, n <= 64: f64[n][GE_DC_LANES] distances (one column per source lane) + u8[64][GE_DC_LANES] work stacks
   int kou;      // own Steiner baseline (is_eval_env, 1 < n_dests < n-1): u64[2][n*W] path union / tree, f64[T] keys, i32[2][T]
   int pre;      // i32[nblk+1] exclusive prefix of the per-workgroup reset counts
   int total;
@@ -86,6 +90,7 @@ static inline void ge_make_lds(GeParams &P) {
   L.bits = take(6 * P.W * 8);
   L.misc = take(16 * 4);
   L.fw = (P.env_type == GE_PERISHABLE_DELIVERY) ? take(P.n * P.n * 8) : 0;
+  L.dcs = (P.env_type == GE_DISTRIBUTION_CENTER && P.n <= 64) ? take(P.n * GE_DC_LANES * 8 + 64 * GE_DC_LANES) : 0;
   L.kou = (P.env_type == GE_STEINER_TREE && P.is_eval && P.n_dests > 1 && P.n_dests < P.n - 1) ? take(2 * P.n * P.W * 8 + P.T * 16) : 0;
   // the queue prefix is only needed while a workgroup looks up its slot: it overlays the scratch that follows
   { int pb = ((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4; L.pre = L.mt; if (pb > GE_MT_N * 8) { L.pre = take(pb); } }

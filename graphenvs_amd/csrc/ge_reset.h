@@ -1277,6 +1277,44 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
     uint64_t *acc = c.bits + 5 * W;
     if (lane < W) acc[lane] = 0ull;
     ge_wave_sync();
+    if (n <= GE_WAVE) {
+      // one LANE per source: every lane runs its own label-correcting search (a stack of nodes to relax, LIFO; the least
+      // fixpoint does not depend on the order) over distances S[node][lane] in LDS -- a lane only ever touches its own
+      // column, i.e. its own bank pair, so the searches never conflict.  Several times fewer instructions than 64 wave-wide
+      // Bellman-Ford runs; GE_DC_LANES sources at a time keep the columns at 16 KB of LDS.
+      double *S = (double *)(ge_dyn_smem() + P.lds.dcs);
+      uint8_t *stk = (uint8_t *)(S + n * GE_DC_LANES);
+      const double cutoff = P.max_distance;
+      uint64_t mine = 0;
+      for (int s0 = 0; s0 < n; s0 += GE_DC_LANES) {  // GE_DC_LANES sources at a time: the columns are what costs LDS
+        const int s = s0 + lane;
+        if (lane < GE_DC_LANES && s < n) {
+          for (int v = 0; v < n; v++) S[v * GE_DC_LANES + lane] = __builtin_inf();
+          S[s * GE_DC_LANES + lane] = 0.0;
+          int top = 1; uint64_t instack = 1ull << s, reached = 1ull << s;
+          stk[lane] = (uint8_t)s;
+          while (top > 0) {
+            const int u = stk[(--top) * GE_DC_LANES + lane];
+            instack &= ~(1ull << u);
+            const double du = S[u * GE_DC_LANES + lane];
+            for (int k = c.rowptr[u]; k < c.rowptr[u + 1]; k++) {
+              const int v = c.colw[k] >> 4;
+              const double d = du + ge_wlut(c.colw[k] & 15);
+              if (d <= cutoff && d < S[v * GE_DC_LANES + lane]) {
+                S[v * GE_DC_LANES + lane] = d; reached |= 1ull << v;
+                if (!((instack >> v) & 1ull)) { stk[top * GE_DC_LANES + lane] = (uint8_t)v; top++; instack |= 1ull << v; }
+              }
+            }
+          }
+          G.range_bits[nbase + s] = reached;
+          if ((tbits[0] >> s) & 1ull) mine |= reached;
+        }
+        ge_wave_sync();
+      }
+      for (int off = 32; off >= 1; off >>= 1) mine |= ge_shfl_u64(mine, lane ^ off);
+      if (lane == 0) acc[0] = mine;
+      ge_wave_sync();
+    } else
     for (int s = 0; s < n; s++) {
       ge_dijkstra_wave(c, n, s, lane, P.max_distance);
       const bool s_is_target = (tbits[s >> 6] >> (s & 63)) & 1ull;
