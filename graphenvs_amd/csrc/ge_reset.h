@@ -727,10 +727,14 @@ GE_DEV bool ge_ppd_place(const GeParams &P, const GeRctx &c, double *D, double r
   }
   ge_wave_sync();
   for (int w = 0; w < n; w++) {  // row w and column w do not change during sweep w (x + 0 == x, strict >): the cells are independent
-    for (int idx = lane; idx < n * n; idx += GE_WAVE) {
-      const int u = idx / n, v = idx - u * n;
-      const double d = D[u * n + w] + D[w * n + v];
-      if (D[idx] > d) D[idx] = d;
+    for (int v0 = 0; v0 < n; v0 += GE_WAVE) {
+      const int v = v0 + lane;
+      const double dwv = v < n ? D[w * n + v] : 0.0;
+      if (v < n && dwv < __builtin_inf())  // inf + x never improves anything
+        for (int u = 0; u < n; u++) {
+          const double d = D[u * n + w] + dwv;  // D[u][w]: the same word for every lane (broadcast read)
+          if (D[u * n + v] > d) D[u * n + v] = d;
+        }
     }
     ge_wave_sync();
   }
