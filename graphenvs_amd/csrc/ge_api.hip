@@ -64,6 +64,9 @@ static int derive(const ge_config *cfg, GeParams &P) {
   // reference would spin for hours per reset and a device loop of that length is a hung GPU -- refuse it loudly instead.
   if (m < max_edges && (double)ng * exp(-2.0 * (double)m / (double)ng) > 16.2)
     return fail(GE_E_UNSUPPORTED, "n_edges is so small for n_nodes that a random G(n, m) is connected with probability < 1e-7: the reference's rejection loop would not terminate in practice");
+  // TSP also rejects graphs with a node of degree 1 (tsp.py:65-68): P(none) ~ exp(-n d e^(-d)) with d = 2m/n
+  if (t == GE_TSP && m < max_edges && (double)n * (2.0 * m / n) * exp(-2.0 * (double)m / (double)n) > 16.2)
+    return fail(GE_E_UNSUPPORTED, "n_edges is so small for n_nodes that a random G(n, m) has no degree-1 node with probability < 1e-7: the TSP rejection loop would not terminate in practice");
   // constructor asserts of the reference
   if (t == GE_SHORTEST_PATH && cfg->parenting != -1) return fail(GE_E_BADARG, "Parenting is not available for shortest path (shortest_path.py:26)");
   if (t == GE_STEINER_TREE && cfg->parenting != -1) return fail(GE_E_BADARG, "Parenting not available for this environment (steiner_tree.py:29)");
