@@ -1004,8 +1004,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
 
   GE_STAMP(2);
-  if (mode != GE_RESET_INJECT && t != GE_PERISHABLE_DELIVERY) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
-  // ------------------------------------------------------------------ CSR in insertion order
+  // ------------------------------------------------------------------ CSR in insertion order (needs the topology only: it runs
+  // while the numpy wave, the longer of the two, is still drawing)
   if (mode != GE_RESET_INJECT) {
     for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
     ge_wave_sync();
@@ -1060,6 +1060,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
 
   GE_STAMP(3);
+  if (mode != GE_RESET_INJECT && t != GE_PERISHABLE_DELIVERY) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
   // ------------------------------------------------------------------ weight codes + terminals
   if (mode != GE_RESET_INJECT) {
     for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
