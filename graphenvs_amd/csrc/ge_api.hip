@@ -111,6 +111,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   // as long as the partial-sum scratch stays below 512 MiB
   P.feat_parts = 1;
   if (n > 64) { int parts = 8; while (parts > 1 && (int64_t)cfg->num_envs * parts * n * 8 > (512ll << 20)) parts >>= 1; P.feat_parts = parts; }
+  if (P.complete && ng == n) P.feat_parts = 1;  // no BFS sources to share: betweenness and closeness of a complete graph are constants
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");

@@ -111,37 +111,38 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
     ge_sync();
     if (part != 0) return;  // part 0 also does clustering and pagerank
   }
-  if (wv == 0) {
-  if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = lane; v < n; v += GE_WAVE) c.bc[v] *= scale; }
-  // clustering (directed formula on the symmetric graph) -> coeff[]
-  for (int i = lane; i < n; i += GE_WAVE) {
+  // node-level work, rows dealt to every thread of the workgroup (each node's sums keep their order; the iteration count and
+  // the pairwise error sum are the same in every wave)
+  if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = tid; v < n; v += nthreads) c.bc[v] *= scale; }
+  // clustering (directed formula on the symmetric graph) -> wave 0's coeff slice (the Brandes scratch is free now)
+  double *clus = c.bcw0 - n;
+  for (int i = tid; i < n; i += nthreads) {
     int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
     for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) { int j = c.colw[k] >> 4; for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]); }
     int64_t t8 = 8 * common, dt = 2 * dg, db = dg;
-    c.coeff[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
+    clus[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
   }
   // pagerank ([nx] _pagerank_scipy): pull over in-neighbours in ascending order
   const bool prw = (t == GE_TSP);
   const double pinit = 1.0 / (double)n;
   int ndang = 0;
-  for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
-    int i = k0 + lane; bool dang = false;
-    if (i < n) {
-      double S = 0.0;
-      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : ge_wlut(c.scw[k] & 15)) : 1.0) * 1.0;
-      c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
-      c.prx[i] = pinit;
-      dang = (c.rowptr[i + 1] == c.rowptr[i]);
-    }
-    ndang += ge_popc64(ge_ballot(dang));
+  for (int k0 = 0; k0 < n; k0 += GE_WAVE) {  // every wave counts the dangling nodes itself
+    int i = k0 + lane;
+    ndang += ge_popc64(ge_ballot(i < n && c.rowptr[i + 1] == c.rowptr[i]));
   }
-  ge_wave_sync();
+  for (int i = tid; i < n; i += nthreads) {
+    double S = 0.0;
+    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : ge_wlut(c.scw[k] & 15)) : 1.0) * 1.0;
+    c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
+    c.prx[i] = pinit;
+  }
+  ge_sync();
   const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
   bool conv = false;
   for (int it = 0; it < 100 && !conv; it++) {
     double dsum = 0.0;
     if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
-    for (int i = lane; i < n; i += GE_WAVE) {
+    for (int i = tid; i < n; i += nthreads) {
       double acc = 0.0;
       for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
         int j = c.scw[k] >> 4;
@@ -152,20 +153,20 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
       c.prn[i] = xn;
       c.diff[i] = __builtin_fabs(xn - c.prx[i]);
     }
-    ge_wave_sync();
+    ge_sync();
     double err = ge_pw<5>(c.diff, n, lane);
-    for (int i = lane; i < n; i += GE_WAVE) c.prx[i] = c.prn[i];
-    ge_wave_sync();
+    ge_sync();  // every wave has read diff[] and prx[] before they are rewritten
+    for (int i = tid; i < n; i += nthreads) c.prx[i] = c.prn[i];
+    ge_sync();
     if (err < (double)n * tol) conv = true;
   }
 
   // sf = torch.tensor(sf) -> float32; x[:, -5:] = sf
-  for (int v = lane; v < n; v += GE_WAVE) {
+  for (int v = tid; v < n; v += nthreads) {
     float *xr = G.x + (nbase + v) * F + P.nflag;
     xr[0] = (float)(2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]));
     if (nparts == 1) { xr[1] = (float)c.bc[v]; xr[2] = (float)c.clos[v]; }
-    xr[3] = (float)c.prx[v]; xr[4] = (float)c.coeff[v];
-  }
+    xr[3] = (float)c.prx[v]; xr[4] = (float)clus[v];
   }
   ge_sync();
 }

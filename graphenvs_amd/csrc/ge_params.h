@@ -111,6 +111,9 @@ static inline void ge_make_ldsf(GeParams &P) {
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
   if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here
+  // complete graph on all nodes (TSP config 3): Brandes is skipped, the workgroup is the pagerank over n rows of n-1 entries --
+  // as many waves as fit one workgroup per CU
+  if (P.complete && P.ng == P.n && P.n > 64) { waves = (160 * 1024 - shared) / (per_wave > 0 ? per_wave : 1); if (waves > 8) waves = 8; if (waves < 1) waves = 1; }
   L.waves = waves;
   L.dist = take(waves * P.n * 4);
   L.f64a = take((6 + 4 * waves) * P.n * 8);
