@@ -147,6 +147,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
   if (P.env_type == GE_DISTRIBUTION_CENTER && (!bufs->range_bits || !bufs->cover_bits)) return fail(GE_E_BADARG, "DistributionCenter needs range_bits and cover_bits");
+  if (P.env_type == GE_DISTRIBUTION_CENTER && P.n <= 64 && !bufs->cur_rec) return fail(GE_E_BADARG, "DistributionCenter with n_nodes <= 64 needs cur_rec (which rows of range_bits exist)");
   if (P.env_type == GE_MULTICAST_ROUTING && P.parenting == 2 && !bufs->rev_edge) return fail(GE_E_BADARG, "MulticastRouting parenting 2 needs rev_edge");
   if (P.env_type == GE_MULTICAST_ROUTING && P.parenting >= 3 && !bufs->node_aux) return fail(GE_E_BADARG, "MulticastRouting parenting >= 3 needs node_aux");
   if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
@@ -291,6 +292,11 @@ static bool path64(const ge_engine *e) {
 extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {
   if (!e || !actions) return fail(GE_E_BADARG, "null argument");
   wait_seeded(e, stream);
+  if (e->P.env_type == GE_DISTRIBUTION_CENTER && e->P.n <= 64) {  // the chosen centres' coverage ranges, computed when they are chosen
+    GE_LAUNCH(ge_k_dc_range, (e->P.B + GE_WAVE - 1) / GE_WAVE, GE_WAVE, (size_t)e->P.n * GE_WAVE * 8 + GE_WAVE * 64, stream, e->P, actions);
+    int rc = check_launch("coverage range kernel");
+    if (rc != GE_OK) return rc;
+  }
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0);
   else GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_step<ENV>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions));

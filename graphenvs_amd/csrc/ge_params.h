@@ -8,7 +8,7 @@
 #define GE_MT_N 624
 #define GE_MT_M 397
 #ifndef GE_DC_LANES
-#define GE_DC_LANES 32  // DistributionCenter, n <= 64: sources searched at a time (lanes), 64 / GE_DC_LANES passes; sizes the LDS columns
+#define GE_DC_LANES 16  // DistributionCenter, n <= 64: target ranges searched at a time in the reset kernel (one lane each); sizes the LDS columns
 #endif
 #ifndef GE_STEP_BLOCK
 #define GE_STEP_BLOCK 256

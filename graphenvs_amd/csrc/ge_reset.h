@@ -857,6 +857,31 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane)
   GE_STAMP(23);
 }
 
+// DistributionCenter, n <= 64: nodes within `cutoff` of `s` (float64 sums taken from s outwards), by a label-correcting search
+// of ONE lane: a LIFO stack of nodes to relax over distances S[node * ss] (the least fixpoint does not depend on the order).
+// rowptr / colw may be the LDS copies of the reset kernel or the global slabs; S and stk are the lane's own columns.
+template <class RP, class CW>
+GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, const CW *colw, double *S, int ss, uint8_t *stk, int ks) {
+  for (int v = 0; v < n; v++) S[v * ss] = __builtin_inf();
+  S[s * ss] = 0.0;
+  int top = 1; uint64_t instack = 1ull << s, reached = 1ull << s;
+  stk[0] = (uint8_t)s;
+  while (top > 0) {
+    const int u = stk[(--top) * ks];
+    instack &= ~(1ull << u);
+    const double du = S[u * ss];
+    for (int k = rowptr[u]; k < rowptr[u + 1]; k++) {
+      const int v = colw[k] >> 4;
+      const double d = du + ge_wlut(colw[k] & 15);
+      if (d <= cutoff && d < S[v * ss]) {
+        S[v * ss] = d; reached |= 1ull << v;
+        if (!((instack >> v) & 1ull)) { stk[top * ks] = (uint8_t)v; top++; instack |= 1ull << v; }
+      }
+    }
+  }
+  return reached;
+}
+
 template <int ENV>
 GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
@@ -1287,36 +1312,27 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       // fixpoint does not depend on the order) over distances S[node][lane] in LDS -- a lane only ever touches its own
       // column, i.e. its own bank pair, so the searches never conflict.  Several times fewer instructions than 64 wave-wide
       // Bellman-Ford runs; GE_DC_LANES sources at a time keep the columns at 16 KB of LDS.
+      // Only the rows the mask needs now -- the targets' (parenting 2) -- are computed here; the row of a chosen centre is
+      // computed when it is chosen (ge_k_dc_range, in front of the step kernel), as the reference does (distribution_center.py:
+      // 117-118, 155).  cur_rec[2 * env] records which rows of range_bits exist.
       double *S = (double *)(ge_dyn_smem() + P.lds.dcs);
       uint8_t *stk = (uint8_t *)(S + n * GE_DC_LANES);
-      const double cutoff = P.max_distance;
+      const uint64_t want = (P.parenting == 2) ? tbits[0] : 0ull;
       uint64_t mine = 0;
-      for (int s0 = 0; s0 < n; s0 += GE_DC_LANES) {  // GE_DC_LANES sources at a time: the columns are what costs LDS
-        const int s = s0 + lane;
-        if (lane < GE_DC_LANES && s < n) {
-          for (int v = 0; v < n; v++) S[v * GE_DC_LANES + lane] = __builtin_inf();
-          S[s * GE_DC_LANES + lane] = 0.0;
-          int top = 1; uint64_t instack = 1ull << s, reached = 1ull << s;
-          stk[lane] = (uint8_t)s;
-          while (top > 0) {
-            const int u = stk[(--top) * GE_DC_LANES + lane];
-            instack &= ~(1ull << u);
-            const double du = S[u * GE_DC_LANES + lane];
-            for (int k = c.rowptr[u]; k < c.rowptr[u + 1]; k++) {
-              const int v = c.colw[k] >> 4;
-              const double d = du + ge_wlut(c.colw[k] & 15);
-              if (d <= cutoff && d < S[v * GE_DC_LANES + lane]) {
-                S[v * GE_DC_LANES + lane] = d; reached |= 1ull << v;
-                if (!((instack >> v) & 1ull)) { stk[top * GE_DC_LANES + lane] = (uint8_t)v; top++; instack |= 1ull << v; }
-              }
-            }
-          }
+      for (uint64_t left = want; left;) {  // GE_DC_LANES sources at a time, lane k takes the k-th wanted node
+        int s = -1;
+        { uint64_t l2 = left; for (int k = 0; k < GE_DC_LANES && l2; k++) { const int b = ge_ctz64(l2); l2 &= l2 - 1; if (k == lane) s = b; } }
+        uint64_t taken_now = 0; { uint64_t l2 = left; for (int k = 0; k < GE_DC_LANES && l2; k++) { taken_now |= l2 & (~l2 + 1); l2 &= l2 - 1; } }
+        left &= ~taken_now;
+        if (s >= 0) {
+          const uint64_t reached = ge_dc_search(P.max_distance, n, s, c.rowptr, c.colw, S + lane, GE_DC_LANES, stk + lane, GE_DC_LANES);
           G.range_bits[nbase + s] = reached;
-          if ((tbits[0] >> s) & 1ull) mine |= reached;
+          mine |= reached;
         }
         ge_wave_sync();
       }
       for (int off = 32; off >= 1; off >>= 1) mine |= ge_shfl_u64(mine, lane ^ off);
+      if (lane == 0) G.cur_rec[(int64_t)env * 2] = want;
       if (lane == 0) acc[0] = mine;
       ge_wave_sync();
     } else

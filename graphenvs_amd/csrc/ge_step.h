@@ -625,6 +625,50 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
   }
 }
 
+// DistributionCenter, n <= 64: the coverage range of the node each slot is about to choose, unless the row already exists
+// (a target's, or a node chosen earlier in the episode).  64-thread workgroups, one lane per slot, columns in LDS.
+GE_KERNEL ge_k_dc_range(GeParams P, const int64_t *actions) {
+  const int lane = ge_tid(), i = ge_bid() * GE_WAVE + lane, n = P.n;
+  double *S = (double *)ge_dyn_smem();
+  uint8_t *stk = (uint8_t *)(S + n * GE_WAVE);
+  if (i >= P.B) return;
+  const int64_t a64 = actions[i];
+  if (P.buf.status[i] != 0 || a64 < 0 || a64 >= (int64_t)n) return;
+  const int a = (int)a64;
+  if (!((P.buf.mask_bits[i] >> a) & 1ull)) return;  // the step kernel will flag it invalid
+  const uint64_t have = P.buf.cur_rec[(int64_t)i * 2];
+  if ((have >> a) & 1ull) return;
+  const int64_t nbase = (int64_t)i * n;
+  // the same label-correcting search as ge_dc_search, over node_rec: one 16-byte gather per relaxed node gives its neighbours
+  // (bit row) and their weight codes (nibbles in ascending-neighbour order); rows with more than 16 neighbours read scode
+  double *Sc = S + lane; uint8_t *st = stk + lane;
+  const double cutoff = P.max_distance;
+  for (int v = 0; v < n; v++) Sc[v * GE_WAVE] = __builtin_inf();
+  Sc[a * GE_WAVE] = 0.0;
+  int top = 1; uint64_t instack = 1ull << a, reached = 1ull << a;
+  st[0] = (uint8_t)a;
+  while (top > 0) {
+    const int u = st[(--top) * GE_WAVE];
+    instack &= ~(1ull << u);
+    const double du = Sc[u * GE_WAVE];
+    const ulonglong2 rec = ((const ulonglong2 *)P.buf.node_rec)[nbase + u];
+    const bool wide = ge_popc64(rec.x) > 16;
+    const uint8_t *codes = wide ? P.buf.scode + (int64_t)i * P.E + P.buf.row_ptr[(int64_t)i * (n + 1) + u] : nullptr;
+    int k = 0;
+    for (uint64_t r = rec.x; r; r &= r - 1, k++) {
+      const int v = ge_ctz64(r);
+      const int code = wide ? (int)codes[k] : (int)((rec.y >> (4 * k)) & 15ull);
+      const double d = du + ge_wlut(code);
+      if (d <= cutoff && d < Sc[v * GE_WAVE]) {
+        Sc[v * GE_WAVE] = d; reached |= 1ull << v;
+        if (!((instack >> v) & 1ull)) { st[top * GE_WAVE] = (uint8_t)v; top++; instack |= 1ull << v; }
+      }
+    }
+  }
+  P.buf.range_bits[nbase + a] = reached;
+  P.buf.cur_rec[(int64_t)i * 2] = have | (1ull << a);
+}
+
 GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
   int i = ge_bid() * ge_bdim() + ge_tid();
   if (i >= P.B) return;
