@@ -86,6 +86,7 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (t == GE_MULTICAST_ROUTING && (cfg->parenting < 1 || cfg->parenting > 4)) return fail(GE_E_BADARG, "Invalid parenting type (multicast_routing.py:34-35)");
   // not built yet
   if (t == GE_TSP && cfg->spatial && n > 512) return fail(GE_E_UNSUPPORTED, "spatial TSP is built for n_nodes <= 512");
+  if (t == GE_PERISHABLE_DELIVERY && n > 128) return fail(GE_E_UNSUPPORTED, "PerishableProductDelivery is built for n_nodes <= 128 (two-word node sets in the placement, Floyd-Warshall matrix in LDS)");
   if ((t == GE_LONGEST_PATH || t == GE_TSP) && cfg->parenting >= 2 && n > 64 * GE_MAXW) return fail(GE_E_UNSUPPORTED, "parenting >= 2 is built for n_nodes <= 512");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;

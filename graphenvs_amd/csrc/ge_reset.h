@@ -765,6 +765,7 @@ GE_DEV bool ge_ppd_place(const GeParams &P, const GeRctx &c, double *D, double r
     int k = ge_np_index(c.mt2, nppos, nB + nC + nR, lane);
     int d;
     if (k < nB) d = ge_select2(B0, B1, k);
+    else if (k < nB + nC && P.complete) d = ge_select2(C0, C1, k - nB);  // [nx] complete_graph adds the edges in ascending order (no edge list here)
     else if (k < nB + nC) {  // the (k - nB)-th edge of p, in insertion order, whose other end is in C
       k -= nB; d = -1;
       for (int e0 = 0; e0 < m && d < 0; e0 += GE_WAVE) {

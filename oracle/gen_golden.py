@@ -92,6 +92,10 @@ CASES = {
     "ppd_n12_auto_unweighted": ("PerishableProductDelivery-v0", dict(n_nodes=12, n_edges=-1, weighted=False, n_products=2, parenting=1), list(range(4))),
     "ppd_n64_m192_eval": ("PerishableProductDelivery-v0", dict(n_nodes=64, n_edges=192, parenting=1, is_eval_env=True), list(range(4))),
     "ppd_n100_m300_p4": ("PerishableProductDelivery-v0", dict(n_nodes=100, n_edges=300, n_products=4, parenting=1), [0, 1]),
+    # complete graphs ([nx] complete_graph: sorted adjacency) through the widened envs
+    "ppd_n7_m21_complete": ("PerishableProductDelivery-v0", dict(n_nodes=7, n_edges=21, n_products=2, parenting=1, is_eval_env=True), list(range(8))),
+    "mc_n8_m28_complete_p4_eval": ("MulticastRouting-v0", dict(n_nodes=8, n_edges=28, n_dests=3, is_eval_env=True), list(range(6))),
+    "dc_n8_m28_complete_dist0p6": ("DistributionCenter-v0", dict(n_nodes=8, n_edges=28, max_distance=0.6, target_count=3), list(range(6))),
     "mc_n300_m900_p3_d4_eval": ("MulticastRouting-v0", dict(n_nodes=300, n_edges=900, n_dests=4, parenting=3, is_eval_env=True), [0]),
 }
 

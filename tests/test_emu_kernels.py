@@ -22,7 +22,8 @@ FAST = ["sp_n10_m20_eval", "sp_n5_m7", "sp_n33_m70", "sp_n64_m192_eval", "lp_n10
         "mc_n10_m20_p4", "mc_n10_m20_p3_d2", "mc_n10_m20_p2", "mc_n10_m20_p1", "mc_n10_m20_p4_eval",
         "mc_n12_auto_edges_p4_unweighted", "mc_n64_m192_p4_d40_eval",
         "dc_n10_m20_p2", "dc_n10_m20_p1", "dc_n12_m25_p2_unweighted_t4", "dc_n20_m40_p2_dist1p5_eval", "dc_n64_m192_p2_dist0p7",
-        "ppd_n8_m9_p3", "ppd_n12_auto_unweighted"]
+        "ppd_n8_m9_p3", "ppd_n12_auto_unweighted", "ppd_n7_m21_complete", "mc_n8_m28_complete_p4_eval",
+        "dc_n8_m28_complete_dist0p6"]
 
 
 @pytest.fixture(scope="module")

@@ -346,7 +346,7 @@ def _random_config(rng):
                          "MulticastRouting-v0", "DistributionCenter-v0", "PerishableProductDelivery-v0"]))
     n = int(rng.choice([5, 7, 9, 16, 31, 33, 64, 65, 90, 129, 140]))
     if env_id == "PerishableProductDelivery-v0":
-        n = min(n, 129)
+        n = min(n, 128)
     ng = n - 1 if env_id == "DensestSubgraph-v0" else n
     # G(n, m) is sampled by rejection until connected (TSP: also no degree-1 node, no cut through node 0): keep m where
     # that succeeds within a few attempts -- the reference itself (and the device loop) would spin for ages below it
