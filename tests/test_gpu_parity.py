@@ -374,7 +374,7 @@ def _random_config(rng):
     return env_id, kw
 
 
-@pytest.mark.parametrize("chunk", range(6))
+@pytest.mark.parametrize("chunk", range(12))
 def test_randomized_configs_match_oracle(chunk):
     """differential test: random constructor arguments of all nine envs, device policy, autoreset, every output compared
     with the CPU oracle (which is pinned by the reference fixtures)"""
