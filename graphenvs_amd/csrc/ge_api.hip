@@ -300,7 +300,7 @@ extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) 
   }
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_step<ENV>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions));
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0));
   return check_launch("step kernel");
 }
 
@@ -312,8 +312,13 @@ static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch,
     GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, scratch, policy_seed);
     return check_launch("fused sample+step kernel");
   }
-  int rc = ge_sample_actions(e, policy_seed, scratch, stream);
-  return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
+  if (e->P.env_type == GE_DISTRIBUTION_CENTER && e->P.n <= 64) {  // the coverage range kernel sits between the policy and the step
+    int rc = ge_sample_actions(e, policy_seed, scratch, stream);
+    return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
+  }
+  int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, scratch, policy_seed));
+  return check_launch("fused sample+step kernel");
 }
 
 extern "C" int ge_reset_pending(ge_engine *e, void *stream) {

@@ -60,8 +60,39 @@ GE_DEV void ge_reach_thread(const uint64_t *rows, int W, const uint64_t *alive, 
   }
 }
 
-template <int ENV>
-GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
+// ---------------------------------------------------------------------------------------------
+// bench / test policy: uniform choice among valid actions, keyed by (policy_seed, global slot, tstep)
+GE_DEV uint64_t ge_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+GE_DEV int ge_nth_set_bit(uint64_t word, uint32_t r) {
+  for (uint32_t k = 0; k < r; k++) word &= word - 1;
+  return ge_ctz64(word);
+}
+
+// the action of slot i under that policy (-1: empty mask, or a frozen slot)
+GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
+  const uint64_t *mb = P.buf.mask_bits + (int64_t)i * P.AW;
+  uint32_t cnt = 0;
+  for (int w = 0; w < P.AW; w++) cnt += (uint32_t)ge_popc64(mb[w]);
+  if (!cnt || P.buf.status[i] == 1) return -1;
+  uint64_t gi = (uint64_t)(P.env_index_base + i), ts = (uint64_t)P.buf.tstep[i];
+  uint64_t z = ge_mix64(policy_seed + gi * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
+  uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
+  for (int w = 0; w < P.AW; w++) {
+    uint64_t word = mb[w]; uint32_t pc = (uint32_t)ge_popc64(word);
+    if (r < pc) return (int64_t)w * 64 + ge_nth_set_bit(word, r);
+    r -= pc;
+  }
+  return -1;
+}
+
+// SAMPLE: the device policy is evaluated here (one launch per rollout step) and the action is also written to actions_out
+template <int ENV, bool SAMPLE>
+GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, uint64_t policy_seed) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -76,7 +107,8 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
 
   if (i < P.B) {
     const int64_t nbase = (int64_t)i * n;
-    int64_t a64 = actions[i];
+    int64_t a64;
+    if (SAMPLE) { a64 = ge_policy_pick(P, i, policy_seed); actions_out[i] = a64; } else a64 = actions[i];
     uint8_t st = G.status[i];
     double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
     bool cost_hidden = false;  // multicast: info['solution_cost'] stays -1 unless the episode is solved
@@ -460,19 +492,6 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// bench / test policy: uniform choice among valid actions, keyed by (policy_seed, global slot, tstep)
-GE_DEV uint64_t ge_mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
-GE_DEV int ge_nth_set_bit(uint64_t word, uint32_t r) {
-  for (uint32_t k = 0; k < r; k++) word &= word - 1;
-  return ge_ctz64(word);
-}
-
 // Headline fast path: ShortestPath / LongestPath(parenting 0,1) with n <= 64.  One u64 per node set.  The kernel is
 // three phases per slot: (A) every load -- the coalesced slot state, then ONE 16-byte gather for the record of the
 // chosen node; (B) the transition in registers; (C) every store.  No load is issued after the first store: vmcnt
@@ -672,20 +691,7 @@ GE_KERNEL ge_k_dc_range(GeParams P, const int64_t *actions) {
 GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
   int i = ge_bid() * ge_bdim() + ge_tid();
   if (i >= P.B) return;
-  const uint64_t *mb = P.buf.mask_bits + (int64_t)i * P.AW;
-  uint32_t cnt = 0;
-  for (int w = 0; w < P.AW; w++) cnt += (uint32_t)ge_popc64(mb[w]);
-  if (!cnt || P.buf.status[i] == 1) { actions[i] = -1; return; }
-  uint64_t gi = (uint64_t)(P.env_index_base + i), ts = (uint64_t)P.buf.tstep[i];
-  uint64_t z = ge_mix64(policy_seed + gi * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
-  uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
-  int64_t act = -1;
-  for (int w = 0; w < P.AW; w++) {
-    uint64_t word = mb[w]; uint32_t pc = (uint32_t)ge_popc64(word);
-    if (r < pc) { act = (int64_t)w * 64 + ge_nth_set_bit(word, r); break; }
-    r -= pc;
-  }
-  actions[i] = act;
+  actions[i] = ge_policy_pick(P, i, policy_seed);
 }
 
 // utils.vectorize_graph for every slot (utils.py:87-88): [x.ravel | edge_attr.ravel | links.ravel] as f32
