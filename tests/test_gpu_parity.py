@@ -434,3 +434,29 @@ def test_randomized_configs_match_oracle(chunk):
 def test_next_step_autoreset_matches_oracle(env_id, kw):
     import oracle
     gu.check_next_step_autoreset(_ge(), oracle, env_id, kw, 48, 80, "cuda")
+
+
+def test_cpp_host_on_the_c_abi_alone_matches_the_python_host():
+    """examples/abi_demo.cpp allocates every buffer with hipMalloc and calls only include/graphenvs.h (no Python, no torch in
+    that process); its counters must equal what the Python host gets for the same seeds and policy."""
+    import json
+    import os
+    import subprocess
+    ge = _ge()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "abi_demo")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        exe = __graft_entry__.build_abi_demo()
+    B, K = 2048, 60
+    out = subprocess.run([exe, str(B), str(K)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    env = ge.make_vec("ShortestPath-v0", B, n_nodes=64, n_edges=192)
+    env.reset(seed=0)
+    env.random_rollout(K, policy_seed=1)
+    torch.cuda.synchronize()
+    assert got["episodes"] == int(env.t["episode"].sum()) and got["transitions"] == int(env.t["tstep"].sum())
+    # the demo adds left to right; numpy's sum() is pairwise, cumsum() is sequential
+    assert got["cost_sum"] == float(np.cumsum(env.t["cost"].cpu().numpy())[-1])
+    assert got["x_sum"] == float(np.cumsum(env.t["x"].cpu().numpy().astype(np.float64).ravel())[-1])
