@@ -108,10 +108,12 @@ static int derive(const ge_config *cfg, GeParams &P) {
   P.node_id_base = cfg->node_id_base;
   P.edge_row_stride = cfg->edge_row_stride > 0 ? cfg->edge_row_stride : (int64_t)cfg->num_envs * 2 * m;
   P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 256) ? 1 : 0;  // nibble matrix of n*n/2 bytes <= 32 KiB
-  // few slots regenerate per step when graphs are large (long episodes): let up to 8 workgroups share a slot's sources,
-  // as long as the partial-sum scratch stays below 512 MiB
+  // few slots regenerate per step when graphs are large (long episodes): 8 workgroups share a slot's sources.  The number of
+  // parts fixes the order in which a node's float64 betweenness is added up, so it depends on the geometry only, not on the
+  // batch size (a shard of a batch must reproduce the unsharded run bit for bit); only a partial-sum scratch beyond 16 GiB
+  // halves it
   P.feat_parts = 1;
-  if (n > 64) { int parts = 8; while (parts > 1 && (int64_t)cfg->num_envs * parts * n * 8 > (512ll << 20)) parts >>= 1; P.feat_parts = parts; }
+  if (n > 64) { int parts = 8; while (parts > 1 && (int64_t)cfg->num_envs * parts * n * 8 > (16ll << 30)) parts >>= 1; P.feat_parts = parts; }
   if (P.complete && ng == n) P.feat_parts = 1;  // no BFS sources to share: betweenness and closeness of a complete graph are constants
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");

@@ -145,13 +145,17 @@ def test_autoreset_off_freezes_finished_slots():
     assert not term.any() and (rew == 0).all() and torch.equal(x, env.t["x"])
 
 
-def test_shards_are_invariant_to_the_partition():
-    """the RNG is keyed by the global slot index, so a 2-way shard equals the unsharded batch."""
+@pytest.mark.parametrize("env_id,kw", [("ShortestPath-v0", dict(n_nodes=24, n_edges=60)),
+                                       ("SteinerTree-v0", dict(n_nodes=130, n_edges=420, n_dests=6)),   # generic feature path: partial sums
+                                       ("DistributionCenter-v0", dict(n_nodes=40, n_edges=110))])
+def test_shards_are_invariant_to_the_partition(env_id, kw):
+    """the RNG is keyed by the global slot index, so a 2-way shard equals the unsharded batch (bit for bit, the
+    float64 feature sums included: their order depends on the geometry, never on the batch size)."""
     ge = _ge()
-    kw = dict(n_nodes=24, n_edges=60, obs_mode="flat")
-    whole = ge.make_vec("ShortestPath-v0", 64, seed_stride=64, **kw)
-    lo = ge.make_vec("ShortestPath-v0", 32, seed_stride=64, env_index_base=0, **kw)
-    hi = ge.make_vec("ShortestPath-v0", 32, seed_stride=64, env_index_base=32, **kw)
+    kw = dict(obs_mode="flat", **kw)
+    whole = ge.make_vec(env_id, 64, seed_stride=64, **kw)
+    lo = ge.make_vec(env_id, 32, seed_stride=64, env_index_base=0, **kw)
+    hi = ge.make_vec(env_id, 32, seed_stride=64, env_index_base=32, **kw)
     for e in (whole, lo, hi):
         e.reset(seed=123)
     for k in range(40):
