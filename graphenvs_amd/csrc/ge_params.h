@@ -105,8 +105,10 @@ static inline void ge_make_ldsf(GeParams &P) {
   L.rowptr = take((P.n + 1) * 4);
   L.colw = take((P.E > 0 ? P.E : 1) * 2);
   L.scw = take((P.E > 0 ? P.E : 1) * 2);
+  // the wave count fixes the order of the float64 betweenness partial sums: it is decided from the graph geometry alone (with a
+  // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
+  const int shared = o + 1024 + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
   L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
-  const int shared = o + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
   int waves = (160 * 1024 / 2 - shared) / (per_wave > 0 ? per_wave : 1);  // aim at two workgroups per CU
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
