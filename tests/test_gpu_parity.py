@@ -464,3 +464,54 @@ def test_cpp_host_on_the_c_abi_alone_matches_the_python_host():
     # the demo adds left to right; numpy's sum() is pairwise, cumsum() is sequential
     assert got["cost_sum"] == float(np.cumsum(env.t["cost"].cpu().numpy())[-1])
     assert got["x_sum"] == float(np.cumsum(env.t["x"].cpu().numpy().astype(np.float64).ravel())[-1])
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_randomized_invalid_and_noop_actions(chunk):
+    """random constructor calls of all nine envs, a third of the actions replaced by arbitrary integers in [-3, A + 3): the engine
+    flags exactly what the oracle (= the reference's asserts) refuses, leaves those slots untouched, treats -1 as a no-op"""
+    import oracle
+    ge = _ge()
+    rng = np.random.default_rng(41000 + chunk)
+    done_cfgs = 0
+    for _ in range(10):
+        env_id, kw = _random_config(rng)
+        B, K, stride = 8, 40, 97
+        try:
+            env = ge.make_vec(env_id, B, obs_mode="flat", seed_stride=stride, **kw)
+        except RuntimeError:
+            continue
+        s0 = int(rng.integers(0, 2**31))
+        env.reset(seed=s0)
+        refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+        seeds = [s0 + i for i in range(B)]
+        for r, sd in zip(refs, seeds):
+            r.reset(seed=sd)
+        for k in range(K):
+            a = env.sample_random_actions(policy_seed=11).clone().cpu().numpy()
+            wild = rng.random(B) < 0.35
+            a[wild] = rng.integers(-3, env.A + 3, size=int(wild.sum()))
+            before = env.flat_obs().clone()
+            obs, rew, term, trunc, info = env.step(torch.from_numpy(a).cuda())
+            inv, rew, term = info["invalid_action"].cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+            after = env.flat_obs()
+            for i, r in enumerate(refs):
+                tag = (env_id, kw, k, i, int(a[i]))
+                if a[i] == -1:
+                    assert not inv[i] and rew[i] == 0 and not term[i], tag
+                    continue
+                try:
+                    _, rr, dd, _, inf = r.step(int(a[i]))
+                except AssertionError:
+                    assert inv[i] and rew[i] == 0 and not term[i], tag
+                    assert torch.equal(before[i], after[i]), tag
+                    continue
+                assert not inv[i] and rr == rew[i] and dd == bool(term[i]), tag
+                if dd:
+                    seeds[i] = (seeds[i] + stride) % 2**32
+                    r.reset(seed=seeds[i])
+            assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), (env_id, kw, k)
+        assert np.array_equal(env.flat_obs().cpu().numpy(), np.stack([r.obs() for r in refs])), (env_id, kw)
+        env.close()
+        done_cfgs += 1
+    assert done_cfgs >= 5
