@@ -278,7 +278,9 @@ extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t
                                const int32_t *terminals, void *stream) {
   if (!e || !links || !wcode || !x) return fail(GE_E_BADARG, "null argument");
   const int t = e->P.env_type;
-  if ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE) && !terminals) return fail(GE_E_BADARG, "terminals required");
+  if ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER ||
+       t == GE_PERISHABLE_DELIVERY) && !terminals)
+    return fail(GE_E_BADARG, "terminals required (source / destinations, targets, or pickups then drop-offs)");
  
   GeInject inj = {links, wcode, x, terminals};
   return launch_reset(e, nullptr, GE_RESET_INJECT, inj, stream);

@@ -21,8 +21,11 @@ def check_inject(ge, oracle, device, env_id, kw, B=6, steps=30, library=None):
     x = np.stack([r.nodes() for r in refs])
     T = env.T
     terms = None
-    if env_id in ("ShortestPath-v0", "LongestPath-v0", "SteinerTree-v0"):
+    if env_id in ("ShortestPath-v0", "LongestPath-v0", "SteinerTree-v0", "MulticastRouting-v0", "PerishableProductDelivery-v0"):
         terms = np.stack([np.pad(r.terminals(), (0, T - len(r.terminals()))) for r in refs]).astype(np.int32)
+    if env_id == "DistributionCenter-v0":  # the targets, in the order they were drawn; unused tail = -1
+        tc = refs[0].cfg.n_dests
+        terms = np.stack([np.pad(r.terminals()[:tc], (0, T - tc), constant_values=-1) for r in refs]).astype(np.int32)
     obs, info = env.inject_state(links, wcode, x, terms)
     assert np.array_equal(obs.cpu().numpy(), np.stack([r.obs() for r in refs]))
     assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs]))

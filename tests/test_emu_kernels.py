@@ -126,7 +126,11 @@ def test_emulated_ragged_mixed_batch_matches_oracle(emu):
                                        ("SteinerTree-v0", dict(n_nodes=12, n_edges=30, n_dests=4)),
                                        ("TSP-v0", dict(n_nodes=9, n_edges=20, parenting=1)),
                                        ("MaxIndependentSet-v0", dict(n_nodes=9, n_edges=14)),
-                                       ("DensestSubgraph-v0", dict(n_nodes=12, n_edges=24, parenting=1))])
+                                       ("DensestSubgraph-v0", dict(n_nodes=12, n_edges=24, parenting=1)),
+                                       ("MulticastRouting-v0", dict(n_nodes=12, n_edges=30, n_dests=3)),
+                                       ("MulticastRouting-v0", dict(n_nodes=12, n_edges=30, n_dests=3, parenting=2)),
+                                       ("DistributionCenter-v0", dict(n_nodes=15, n_edges=40)),
+                                       ("PerishableProductDelivery-v0", dict(n_nodes=12, n_edges=30, parenting=1))])
 def test_emulated_inject_state_then_step(emu, env_id, kw):
     import oracle
     from inject_check import check_inject

@@ -301,7 +301,12 @@ def test_soak_many_episodes_sampled_slots_match_oracle():
                                        ("SteinerTree-v0", dict(n_nodes=70, n_edges=200, n_dests=6)),
                                        ("TSP-v0", dict(n_nodes=12, n_edges=40, parenting=1)),
                                        ("MaxIndependentSet-v0", dict(n_nodes=20, n_edges=40)),
-                                       ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=80, parenting=1))])
+                                       ("DensestSubgraph-v0", dict(n_nodes=30, n_edges=80, parenting=1)),
+                                       ("MulticastRouting-v0", dict(n_nodes=40, n_edges=110, n_dests=5)),
+                                       ("MulticastRouting-v0", dict(n_nodes=80, n_edges=260, n_dests=7, parenting=2)),
+                                       ("DistributionCenter-v0", dict(n_nodes=50, n_edges=140)),
+                                       ("DistributionCenter-v0", dict(n_nodes=90, n_edges=300, parenting=1)),
+                                       ("PerishableProductDelivery-v0", dict(n_nodes=30, n_edges=90, n_products=3, parenting=1))])
 def test_inject_state_then_step_matches_oracle(env_id, kw):
     """ge_inject_state: the oracle's post-reset states are loaded instead of sampled (SURVEY 7 parity path)."""
     import oracle
