@@ -330,12 +330,18 @@ class VectorGraphEnv:
         """Parity path: load post-reset states produced elsewhere (links [B,E,2] local ids, wcode [B,E] in
         {3..10}, x [B,n,F], terminals [B,T])."""
         dev = self.device
-        links = torch.as_tensor(np.asarray(links), dtype=torch.int64).to(dev).contiguous()
+        links_np, wcode_np = np.asarray(links), np.asarray(wcode)
+        # the kernel indexes LDS rows with these: refuse what the reference could never produce
+        assert links_np.min() >= 0 and links_np.max() < self.n, "edge_links must hold local node ids in [0, n_nodes)"
+        assert wcode_np.min() >= 3 and wcode_np.max() <= 10, "weight codes are k with weight k/10.0, k in 3..10"
+        links = torch.as_tensor(links_np, dtype=torch.int64).to(dev).contiguous()
         wcode = torch.as_tensor(np.asarray(wcode), dtype=torch.uint8).to(dev).contiguous()
         x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dev).contiguous()
         term = None
         if terminals is not None:
-            term = torch.as_tensor(np.asarray(terminals), dtype=torch.int32).to(dev).contiguous()
+            term_np = np.asarray(terminals)
+            assert term_np.min() >= -1 and term_np.max() < self.n, "terminals are local node ids (-1: unused tail)"
+            term = torch.as_tensor(term_np, dtype=torch.int32).to(dev).contiguous()
             assert term.shape == (self.num_envs, self.T)
         assert links.shape == (self.num_envs, self.E, 2) and wcode.shape == (self.num_envs, self.E)
         assert x.shape == (self.num_envs, self.n, self.F)
