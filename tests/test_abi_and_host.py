@@ -62,6 +62,22 @@ def test_host_asserts_match_reference_constructors():
         ge.vector_env.normalize_kwargs("DensestSubgraph-v0", 10, 20, parenting=1, weighted=True)
     kw = ge.vector_env.normalize_kwargs("DensestSubgraph-v0", 10, -1, parenting=1)
     assert kw["n_edges"] == int((10 * 9 // 2) * 0.30) and kw["n_choices"] == 3.0
+    # the three remaining envs (multicast_routing.py:31-35,53-54; distribution_center.py:29-45; perishable_product_delivery.py:27-61)
+    with pytest.raises(ValueError, match="Invalid parenting type"):
+        ge.vector_env.normalize_kwargs("MulticastRouting-v0", 10, 20, parenting=5)
+    kw = ge.vector_env.normalize_kwargs("MulticastRouting-v0", 12)
+    assert kw["n_edges"] == 19 and kw["parenting"] == 4 and kw["n_dests"] == 3
+    with pytest.raises(AssertionError):
+        ge.vector_env.normalize_kwargs("DistributionCenter-v0", 10, 20, parenting=3)
+    assert ge.vector_env.normalize_kwargs("DistributionCenter-v0", 23, 60)["target_count"] == 4
+    with pytest.raises(AssertionError, match="Parenting must be 1"):
+        ge.vector_env.normalize_kwargs("PerishableProductDelivery-v0", 10, 20)
+    with pytest.raises(AssertionError, match="Max 5 products"):
+        ge.vector_env.normalize_kwargs("PerishableProductDelivery-v0", 10, 20, parenting=1, n_products=6)
+    kw = ge.vector_env.normalize_kwargs("PerishableProductDelivery-v0", 64, 192, parenting=1)
+    avg = np.log(64) / np.log(6.0) * (0.3 + 1.0) / 2.0
+    assert kw["_dt_window"] == (float(avg * 0.6), float(avg * 1.4))
+    assert utils.get_env_info("MulticastRouting-v0") == (9, 2, "edge") and utils.get_env_info("PerishableProductDelivery-v0") == (21, 1, "node")
 
 
 def test_product_refuses_to_run_without_gpu():
