@@ -98,7 +98,7 @@ def main():
     traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch") if os.path.exists(pmc_path) else None
 
     out = {
-        "metric": "env-steps/sec (whole node), ShortestPath-v0 n=64 m=192 batch=65536",
+        "metric": "env-steps/sec (whole node), ShortestPath-v0 n=64 m=192 batch=65536, 1/2/4/8 GPU",  # BASELINE.json's metric, verbatim
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
