@@ -47,12 +47,13 @@ class GeLayout(C.Structure):
 
 
 BUFFER_FIELDS = [
-    "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "head", "cur_rec", "terminals",
-    "node_bits", "target_bits", "cost", "counters", "seed", "episode", "tstep", "status", "heuristic", "mt_state",
+    "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "slot_rec", "terminals",
+    "node_bits", "target_bits", "counters", "seed", "episode", "heuristic", "mt_state", "aux_bits",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
-    "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
-    "node_aux", "range_bits", "cover_bits",
+    "final_len", "reset_list", "reset_count", "seed_jobs", "work_list", "work_count", "feat_scratch",
+    "node_aux", "range_bits", "cover_bits", "actions_out",
 ]
+SEED_DEPTH = 3  # GE_SEED_DEPTH
 
 
 class GeBuffers(C.Structure):
@@ -62,8 +63,8 @@ class GeBuffers(C.Structure):
 # every symbol include/graphenvs.h declares
 SYMBOLS = [
     "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_reset", "ge_step", "ge_step_only",
-    "ge_reset_pending", "ge_inject_state", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
-    "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error",
+    "ge_reset_pending", "ge_inject_state", "ge_queue_generation", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
+    "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash",
 ]
 
 
@@ -72,18 +73,52 @@ def sources():
         os.path.join(ROOT, "include", "graphenvs.h")]
 
 
+def source_hash() -> str:
+    """sha256 over the HIP sources and the public header, in file-name order (what the binary was built from)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources():
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:32]
+
+
+def compile_command(out_path: str, extra=()):
+    return [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+            # float64 feature/baseline arithmetic must match CPython/numpy bit for bit: no FMA contraction
+            "-ffp-contract=off", "-I" + CSRC, '-DGE_SOURCE_HASH="%s"' % source_hash(), *extra,
+            os.path.join(CSRC, "ge_api.hip"), "-o", out_path]
+
+
+def built_hash(path: str = None):
+    """source hash embedded in the library file on disk, read from its bytes (no dlopen: a process that already mapped an
+    older file of the same name would be handed that one again).  None: no file, or a binary from before the hash existed."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    data = open(path, "rb").read()
+    k = data.find(b"GE_SOURCE_HASH=")
+    return data[k + 15:k + 47].decode("ascii", "replace") if k >= 0 else None
+
+
+last_build = None  # "compiled" or "reused": what the last build() call did
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Cross-compile the HIP library for gfx950 (works without a GPU)."""
-    srcs = sources()
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+    """Cross-compile the HIP library for gfx950 (works without a GPU).  The binary carries the hash of the sources it
+    was built from (ge_source_hash); it is reused only when that hash equals the hash of the sources on disk."""
+    global last_build, _lib
+    if not force and built_hash() == source_hash():
+        last_build = "reused"
         return LIB_PATH
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # float64 feature/baseline arithmetic must match CPython/numpy bit for bit: no FMA contraction
-           "-ffp-contract=off", "-I" + CSRC, os.path.join(CSRC, "ge_api.hip"), "-o", LIB_PATH]
+    cmd = compile_command(LIB_PATH + ".tmp")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL,
                           stderr=None if verbose else subprocess.DEVNULL)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)  # a new inode: a process that already mapped the old file keeps the old one
+    last_build = "compiled"
+    _lib = None
     return LIB_PATH
 
 
@@ -106,7 +141,9 @@ def bind(lib):
     lib.ge_reset_pending.restype = C.c_int
     lib.ge_reset_pending.argtypes = [vp, vp]
     lib.ge_inject_state.restype = C.c_int
-    lib.ge_inject_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.ge_inject_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.ge_queue_generation.restype = C.c_int
+    lib.ge_queue_generation.argtypes = [vp, C.c_int]
     lib.ge_vectorize.restype = C.c_int
     lib.ge_vectorize.argtypes = [vp, vp, vp]
     lib.ge_sample_actions.restype = C.c_int
@@ -120,27 +157,43 @@ def bind(lib):
     lib.ge_timed_step_burst.argtypes = [vp, u64, i32, vp, vp, C.POINTER(C.c_double)]
     lib.ge_last_error.restype = C.c_char_p
     lib.ge_last_error.argtypes = []
+    lib.ge_source_hash.restype = C.c_char_p
+    lib.ge_source_hash.argtypes = []
     return lib
 
 
 _lib = None
 
 
+ABI_VERSION = 2  # GE_ABI_VERSION of include/graphenvs.h this host was written against
+
+
 def load():
-    """Load the HIP library; raise loudly if it is not there (no fallback)."""
+    """Load the HIP library; raise loudly if it is not there (no fallback).  A binary whose embedded source hash
+    differs from the sources on disk is stale: it is rebuilt when hipcc is there, else refused."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"graphenvs_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        want, have = source_hash(), built_hash()
+        if have != want:
+            if not os.path.exists(HIPCC):
+                raise RuntimeError(f"graphenvs_amd: {LIB_PATH} was built from other sources (hash {have}, sources {want}) "
+                                   "and hipcc is not available to rebuild it")
+            import sys
+            print(f"graphenvs_amd: {LIB_PATH} is stale (hash {have}, sources {want}): rebuilding", file=sys.stderr)
+            build(force=True)
         lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             if not hasattr(lib, s):
                 raise RuntimeError(f"graphenvs_amd: {LIB_PATH} does not export {s}")
         bind(lib)
-        if lib.ge_abi_version() != 1:
+        if lib.ge_abi_version() != ABI_VERSION:
             raise RuntimeError("graphenvs_amd: ABI version mismatch between the python host and the HIP library")
+        if lib.ge_source_hash().decode() != want:
+            raise RuntimeError("graphenvs_amd: the loaded library does not carry the hash of the sources on disk")
         _lib = lib
     return _lib
 

@@ -20,16 +20,30 @@ struct ge_engine {
   int feat_lds, feat_grid, feat_fast, gen_grid;  // structural-feature kernel launch geometry
   hipEvent_t ev[4];
   bool have_events;
-  hipStream_t side;        // side stream of the MT19937 pre-seeding kernel
-  hipEvent_t ev_graph;     // main stream: the graph kernel has consumed the states of this step's slots
-  hipEvent_t ev_seeded;    // side stream: the next states are written
-  bool seed_pending;
+  // MT19937 pre-seeding on a side stream, GE_SEED_DEPTH episodes ahead.  Generation g = (number of step launches) mod
+  // GE_SEED_DEPTH names one entry of the queue ring (reset_list / reset_count / seed_jobs): step g fills it, the side
+  // stream's seeding kernel reads it, and the main stream only has to wait for that kernel before generation g comes round
+  // again GE_SEED_DEPTH steps later -- by then it has long finished, so the wait never stalls.
+  hipStream_t side;
+  bool have_side;
+  hipEvent_t ev_graph[GE_SEED_DEPTH];   // main stream: the reset kernel of generation g has written its jobs and consumed its states
+  hipEvent_t ev_seeded[GE_SEED_DEPTH];  // side stream: the seeding kernel of generation g is done
+  bool seed_pending[GE_SEED_DEPTH];
+  hipEvent_t ev_ahead; bool ahead_pending;  // side stream: the states of episodes 1.. after a full reset / seeded injection
+  int gen;        // generation of the most recent step launch (its queue is the one ge_reset_pending consumes)
+  bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
+  bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
 };
 
 static thread_local char g_err[256] = "";
 static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
 extern "C" const char *ge_last_error(void) { return g_err; }
 extern "C" int ge_abi_version(void) { return GE_ABI_VERSION; }
+#ifndef GE_SOURCE_HASH
+#define GE_SOURCE_HASH "unknown"
+#endif
+static const char g_source_hash[] = "GE_SOURCE_HASH=" GE_SOURCE_HASH;  // the marker lets the host read the hash from the file's bytes
+extern "C" const char *ge_source_hash(void) { return g_source_hash + 15; }
 
 static const int kMaxLds = 160 * 1024;
 
@@ -137,32 +151,52 @@ extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
   return GE_OK;
 }
 
+extern "C" int ge_destroy(ge_engine *e);
+
 extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out) {
   if (!bufs || !out) return fail(GE_E_BADARG, "null argument");
   GeParams P;
   int rc = derive(cfg, P);
   if (rc != GE_OK) return rc;
-  const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->scode, bufs->adj_bits, bufs->head,
-                        bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->cost, bufs->counters, bufs->seed,
-                        bufs->episode, bufs->tstep, bufs->status, bufs->heuristic, bufs->mt_state, bufs->mask, bufs->mask_bits, bufs->reward,
+  const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->scode, bufs->adj_bits, bufs->slot_rec,
+                        bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->counters, bufs->seed,
+                        bufs->episode, bufs->heuristic, bufs->mt_state, bufs->mask, bufs->mask_bits, bufs->reward,
                         bufs->terminated, bufs->invalid, bufs->solved, bufs->final_cost, bufs->final_heur, bufs->final_len,
-                        bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
+                        bufs->reset_list, bufs->reset_count, bufs->seed_jobs, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
   if (P.env_type == GE_DISTRIBUTION_CENTER && (!bufs->range_bits || !bufs->cover_bits)) return fail(GE_E_BADARG, "DistributionCenter needs range_bits and cover_bits");
-  if (P.env_type == GE_DISTRIBUTION_CENTER && P.n <= 64 && !bufs->cur_rec) return fail(GE_E_BADARG, "DistributionCenter with n_nodes <= 64 needs cur_rec (which rows of range_bits exist)");
+  if (P.env_type == GE_DISTRIBUTION_CENTER && P.n <= 64 && !bufs->aux_bits) return fail(GE_E_BADARG, "DistributionCenter with n_nodes <= 64 needs aux_bits (which rows of range_bits exist)");
   if (P.env_type == GE_MULTICAST_ROUTING && P.parenting == 2 && !bufs->rev_edge) return fail(GE_E_BADARG, "MulticastRouting parenting 2 needs rev_edge");
   if (P.env_type == GE_MULTICAST_ROUTING && P.parenting >= 3 && !bufs->node_aux) return fail(GE_E_BADARG, "MulticastRouting parenting >= 3 needs node_aux");
   if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
-  if (P.W == 1 && (!bufs->node_rec || !bufs->cur_rec)) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec and cur_rec");
+  if (P.W == 1 && !bufs->node_rec) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec");
   P.buf = *bufs;
   ge_engine *e = new (std::nothrow) ge_engine();
   if (!e) return fail(GE_E_BADARG, "out of host memory");
-  e->seed_pending = false;
-  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_graph, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_seeded, hipEventDisableTiming) != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot create the side stream"); }
-  e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false;
+  e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false; e->have_side = false;
+  e->gen = 0; e->loaded = false; e->seeded = false; e->ahead_pending = false;
+  for (int g = 0; g < GE_SEED_DEPTH; g++) e->seed_pending[g] = false;
+  {
+    bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
+    int made = 0;
+    for (int g = 0; ok && g < GE_SEED_DEPTH; g++) {
+      ok = hipEventCreateWithFlags(&e->ev_graph[g], hipEventDisableTiming) == hipSuccess; if (ok) made++;
+      if (ok) { ok = hipEventCreateWithFlags(&e->ev_seeded[g], hipEventDisableTiming) == hipSuccess; if (ok) made++; }
+    }
+    if (ok) { ok = hipEventCreateWithFlags(&e->ev_ahead, hipEventDisableTiming) == hipSuccess; if (ok) made++; }
+    if (!ok) {  // undo exactly what was made
+      for (int k = 0; k < made; k++) {
+        if (k == 2 * GE_SEED_DEPTH) (void)hipEventDestroy(e->ev_ahead);
+        else (void)hipEventDestroy((k & 1) ? e->ev_seeded[k >> 1] : e->ev_graph[k >> 1]);
+      }
+      if (made > 0 || e->side) (void)hipStreamDestroy(e->side);
+      delete e;
+      return fail(GE_E_LAUNCH, "cannot create the side stream / events");
+    }
+    e->have_side = true;
+  }
   int per_cu = kMaxLds / (P.lds.total > 0 ? P.lds.total : 1);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
@@ -171,19 +205,19 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   if (P.lds.total > 64 * 1024) {
     hipError_t hr = hipSuccess;
     GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset<ENV>, P.lds.total));
-    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
+    if (hr != hipSuccess) { (void)ge_destroy(e); return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   e->feat_fast = (P.n <= 64 && !P.spatial) ? 1 : 0;  // float64 weights do not fit the fast path's LDS
   e->feat_lds = e->feat_fast ? ge_f64_bytes(P.E, P.env_type == GE_TSP, nblk) : P.ldsf.total;
-  if (e->feat_lds > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "feature kernel does not fit LDS"); }
+  if (e->feat_lds > kMaxLds) { (void)ge_destroy(e); return fail(GE_E_TOOBIG, "feature kernel does not fit LDS"); }
   if (P.ldsf.total > 64 * 1024) {
     hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features, P.ldsf.total);
-    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the feature kernel"); }
+    if (hr != hipSuccess) { (void)ge_destroy(e); return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the feature kernel"); }
   }
   if (e->feat_fast && e->feat_lds > 64 * 1024) {
     hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features64, e->feat_lds);
-    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the n<=64 feature kernel"); }
+    if (hr != hipSuccess) { (void)ge_destroy(e); return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the n<=64 feature kernel"); }
   }
   { int per = kMaxLds / P.ldsf.total; if (per > 16) per = 16; if (per < 1) per = 1; e->gen_grid = 256 * per; if (e->gen_grid > P.B) e->gen_grid = P.B; }
   { int per = kMaxLds / e->feat_lds; if (per > 16) per = 16; if (per < 1) per = 1; e->feat_grid = 256 * per; if (e->feat_grid > P.B) e->feat_grid = P.B; }
@@ -193,8 +227,12 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
 
 extern "C" int ge_destroy(ge_engine *e) {
   if (!e) return GE_OK;
-  (void)hipStreamSynchronize(e->side);
-  (void)hipStreamDestroy(e->side); (void)hipEventDestroy(e->ev_graph); (void)hipEventDestroy(e->ev_seeded);
+  if (e->have_side) {
+    (void)hipStreamSynchronize(e->side);
+    (void)hipStreamDestroy(e->side);
+    for (int g = 0; g < GE_SEED_DEPTH; g++) { (void)hipEventDestroy(e->ev_graph[g]); (void)hipEventDestroy(e->ev_seeded[g]); }
+    (void)hipEventDestroy(e->ev_ahead);
+  }
   if (e->have_events) for (int k = 0; k < 4; k++) (void)hipEventDestroy(e->ev[k]);
   delete e;
   return GE_OK;
@@ -206,52 +244,44 @@ static int check_launch(const char *what) {
   return GE_OK;
 }
 
-static int launch_seed(ge_engine *e, const uint32_t *seeds, int smode, hipStream_t st) {
-  int count = e->P.B;
-  int grid = (count + 255) / 256;
+static int launch_seed(ge_engine *e, const uint32_t *seeds, int smode, int gen, hipStream_t st) {
+  const int64_t count = (smode == GE_SEED_AHEAD) ? (int64_t)e->P.B * GE_SEED_DEPTH : e->P.B;
+  int grid = (int)((count + 255) / 256);
   size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
-  GE_LAUNCH(ge_k_seed, grid, 256, lds, st, e->P, seeds, smode);
+  GE_LAUNCH(ge_k_seed, grid, 256, lds, st, e->P, seeds, smode, gen);
   return check_launch("seed kernel");
 }
 
-// main stream must not touch seed[] / reset_list / mt_state while the side stream's seeding kernel reads or writes them
-static void wait_seeded(ge_engine *e, void *stream) {
-  if (e->seed_pending) { (void)hipStreamWaitEvent((hipStream_t)stream, e->ev_seeded, 0); e->seed_pending = false; }
+// the main stream is about to reuse generation `gen` of the queue ring: the side stream's seeding kernel that read it
+// GE_SEED_DEPTH steps ago must be done (it is, unless the device is badly oversubscribed: this wait does not stall)
+static void wait_generation(ge_engine *e, int gen, void *stream) {
+  if (e->seed_pending[gen]) { (void)hipStreamWaitEvent((hipStream_t)stream, e->ev_seeded[gen], 0); e->seed_pending[gen] = false; }
+}
+// the states of episodes 1.. written after a full reset must be there before the first queued regeneration reads them
+static void wait_ahead(ge_engine *e, void *stream) {
+  if (e->ahead_pending) { (void)hipStreamWaitEvent((hipStream_t)stream, e->ev_ahead, 0); e->ahead_pending = false; }
+}
+static void wait_all_side(ge_engine *e, void *stream) {
+  for (int g = 0; g < GE_SEED_DEPTH; g++) wait_generation(e, g, stream);
+  wait_ahead(e, stream);
 }
 
-static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, void *stream) {
+static int launch_features(ge_engine *e, int mode, int gen, void *stream) {
   int rc = GE_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (mode == GE_RESET_ALL) {  // states of episode 0 on the main stream, right in front of their consumer
-    wait_seeded(e, stream);
-    rc = launch_seed(e, seeds, GE_SEED_GIVEN, st);
-    if (rc != GE_OK) return rc;
-  }
-  int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_reset<ENV>, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj));
-  rc = check_launch("reset kernel");
-  if (rc != GE_OK || mode == GE_RESET_INJECT) return rc;
-  // the slots just regenerated get the states of their next episode, on the side stream, beside the feature kernel
-  (void)hipEventRecord(e->ev_graph, st);
-  (void)hipStreamWaitEvent(e->side, e->ev_graph, 0);
-  rc = launch_seed(e, seeds, mode == GE_RESET_ALL ? GE_SEED_GIVEN_NEXT : GE_SEED_QUEUE_NEXT, e->side);
-  if (rc != GE_OK) return rc;
-  (void)hipEventRecord(e->ev_seeded, e->side);
-  e->seed_pending = true;
   int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);
   if (e->feat_fast) {
-    GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode);
+    GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode, gen);
     rc = check_launch("feature kernel (n <= 64)");
     if (rc != GE_OK) return rc;
     int g2 = e->gen_grid < 64 ? e->gen_grid : 64;  // normally an empty list
-    GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
+    GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST, gen);
     return check_launch("feature kernel (fallback list)");
   }
   {
     int64_t want = (int64_t)fgrid * e->P.feat_parts;
     if (mode == GE_RESET_QUEUE && want > 4096) want = 4096;  // queue mode: the list is short, workgroups stride over it
     if (want > 65535 * 16) want = 65535 * 16;
-    GE_LAUNCH(ge_k_features, (int)want, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode);
+    GE_LAUNCH(ge_k_features, (int)want, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode, gen);
   }
   rc = check_launch("feature kernel");
   if (rc != GE_OK || e->P.feat_parts == 1) return rc;
@@ -259,31 +289,84 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
     size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
     int64_t items = (int64_t)(mode == GE_RESET_QUEUE ? 4096 : e->P.B) * e->P.n;
     int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
-    GE_LAUNCH(ge_k_feat_combine, grid, 256, lds, stream, e->P, mode);
+    GE_LAUNCH(ge_k_feat_combine, grid, 256, lds, stream, e->P, mode, gen);
   }
   return check_launch("feature combine kernel");
 }
 
+// mode GE_RESET_ALL / GE_RESET_INJECT: every slot; GE_RESET_QUEUE: the slots step generation `gen` queued
+static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, int gen, void *stream) {
+  int rc = GE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool restart = (mode == GE_RESET_ALL) || (mode == GE_RESET_INJECT && inj.seeds);
+  if (mode != GE_RESET_QUEUE) wait_all_side(e, stream);  // nothing of the side stream may still read or write what a full reset / injection rewrites
+  else wait_ahead(e, stream);
+  if (mode == GE_RESET_ALL) {  // states of episode 0 on the main stream, right in front of their consumer
+    rc = launch_seed(e, seeds, GE_SEED_GIVEN, 0, st);
+    if (rc != GE_OK) return rc;
+  }
+  int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
+  GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_reset<ENV>, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj, gen));
+  rc = check_launch("reset kernel");
+  if (rc != GE_OK) return rc;
+  if (mode != GE_RESET_INJECT) {
+    rc = launch_features(e, mode, gen, stream);
+    if (rc != GE_OK) return rc;
+  }
+  // side stream: generator states of the episodes ahead.  The event is recorded behind the feature kernel -- the reset kernel's
+  // consumer runs back to back with it, and the seeding kernel has GE_SEED_DEPTH - 1 whole steps before anyone waits for it.
+  if (mode == GE_RESET_QUEUE) {
+    (void)hipEventRecord(e->ev_graph[gen], st);
+    (void)hipStreamWaitEvent(e->side, e->ev_graph[gen], 0);
+    rc = launch_seed(e, nullptr, GE_SEED_JOBS, gen, e->side);
+    if (rc != GE_OK) return rc;
+    (void)hipEventRecord(e->ev_seeded[gen], e->side);
+    e->seed_pending[gen] = true;
+  } else if (restart) {
+    (void)hipEventRecord(e->ev_graph[0], st);
+    (void)hipStreamWaitEvent(e->side, e->ev_graph[0], 0);
+    rc = launch_seed(e, nullptr, GE_SEED_AHEAD, 0, e->side);
+    if (rc != GE_OK) return rc;
+    (void)hipEventRecord(e->ev_ahead, e->side);
+    e->ahead_pending = true;
+    e->seeded = true;
+  }
+  return GE_OK;
+}
+
+static int clear_queues(ge_engine *e, void *stream) {  // a full reset / injection leaves every generation of the queue ring empty
+  const size_t bytes = sizeof(int32_t) * (size_t)GE_SEED_DEPTH * (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK);
+  if (hipMemsetAsync(e->P.buf.reset_count, 0, bytes, (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
+  return GE_OK;
+}
+
 extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
   if (!e || !seeds) return fail(GE_E_BADARG, "null argument");
- 
-  GeInject none = {nullptr, nullptr, nullptr, nullptr};
-  // next-step mode consumes the finished-slot queue at the start of ge_step: a full reset leaves it empty
-  if (e->P.autoreset == 2 && hipMemsetAsync(e->P.buf.reset_count, 0, sizeof(int32_t) * (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK), (hipStream_t)stream) != hipSuccess)
-    return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
-  return launch_reset(e, seeds, GE_RESET_ALL, none, stream);
+  GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  wait_all_side(e, stream);
+  int rc = clear_queues(e, stream);
+  if (rc != GE_OK) return rc;
+  rc = launch_reset(e, seeds, GE_RESET_ALL, none, 0, stream);
+  if (rc == GE_OK) e->loaded = true;
+  return rc;
 }
 
 extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
-                               const int32_t *terminals, void *stream) {
+                               const int32_t *terminals, const uint32_t *seeds, void *stream) {
   if (!e || !links || !wcode || !x) return fail(GE_E_BADARG, "null argument");
   const int t = e->P.env_type;
   if ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER ||
        t == GE_PERISHABLE_DELIVERY) && !terminals)
     return fail(GE_E_BADARG, "terminals required (source / destinations, targets, or pickups then drop-offs)");
- 
-  GeInject inj = {links, wcode, x, terminals};
-  return launch_reset(e, nullptr, GE_RESET_INJECT, inj, stream);
+  if (!seeds && e->P.autoreset && !e->seeded)
+    return fail(GE_E_STATE, "ge_inject_state without seeds on an engine with autoreset whose generator states were never seeded: pass seeds, or call ge_reset first");
+  GeInject inj = {links, wcode, x, terminals, seeds};
+  wait_all_side(e, stream);
+  int rc = clear_queues(e, stream);  // slots queued before the injection must not be regenerated over the injected state
+  if (rc != GE_OK) return rc;
+  rc = launch_reset(e, nullptr, GE_RESET_INJECT, inj, 0, stream);
+  if (rc == GE_OK) e->loaded = true;
+  return rc;
 }
 
 static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P.W * 8 + GE_STEP_BLOCK + 64; }
@@ -294,55 +377,82 @@ static bool path64(const ge_engine *e) {
   return (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1 && e->P.parenting < 2;
 }
 
+// call-order guard (the reference raises in the same situations): stepping needs an episode in the slots, and autoreset needs a
+// seeded generator ring -- an unseeded MT19937 state would draw the same node pair for ever
+static int check_state(const ge_engine *e) {
+  if (!e->loaded) return fail(GE_E_STATE, "the engine holds no episode yet: call ge_reset (or ge_inject_state) first");
+  if (e->P.autoreset && !e->seeded) return fail(GE_E_STATE, "autoreset needs seeded generator states: call ge_reset, or ge_inject_state with seeds");
+  return GE_OK;
+}
+
+// every step launch opens the next generation of the queue ring
+static int next_generation(ge_engine *e, void *stream) {
+  e->gen = (e->gen + 1) % GE_SEED_DEPTH;
+  wait_generation(e, e->gen, stream);
+  return e->gen;
+}
+
 extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {
   if (!e || !actions) return fail(GE_E_BADARG, "null argument");
-  wait_seeded(e, stream);
+  int rc = check_state(e);
+  if (rc != GE_OK) return rc;
   if (e->P.env_type == GE_DISTRIBUTION_CENTER && e->P.n <= 64) {  // the chosen centres' coverage ranges, computed when they are chosen
     GE_LAUNCH(ge_k_dc_range, (e->P.B + GE_WAVE - 1) / GE_WAVE, GE_WAVE, (size_t)e->P.n * GE_WAVE * 8 + GE_WAVE * 64, stream, e->P, actions);
-    int rc = check_launch("coverage range kernel");
+    rc = check_launch("coverage range kernel");
     if (rc != GE_OK) return rc;
   }
+  const int gen = next_generation(e, stream);
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (int64_t *)nullptr, (uint64_t)0));
+  if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0, gen);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0, gen));
   return check_launch("step kernel");
 }
 
-// sample + step in one launch where the fused kernel exists, else two launches; `scratch` receives the actions
+// sample + step in one launch where the fused kernel exists (the drawn actions go to ge_buffers.actions_out when that is set),
+// else two launches through `scratch`
 static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch, void *stream) {
-  wait_seeded(e, stream);
-  if (path64(e)) {
-    int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-    GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, scratch, policy_seed);
-    return check_launch("fused sample+step kernel");
-  }
+  int rc = check_state(e);
+  if (rc != GE_OK) return rc;
   if (e->P.env_type == GE_DISTRIBUTION_CENTER && e->P.n <= 64) {  // the coverage range kernel sits between the policy and the step
-    int rc = ge_sample_actions(e, policy_seed, scratch, stream);
+    if (!scratch) return fail(GE_E_BADARG, "this env type needs actions_scratch");
+    rc = ge_sample_actions(e, policy_seed, scratch, stream);
     return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
   }
+  const int gen = next_generation(e, stream);
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, scratch, policy_seed));
+  if (path64(e)) GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed, gen);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed, gen));
   return check_launch("fused sample+step kernel");
 }
 
+// regenerate the slots the most recent step launch queued
 extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
   if (!e) return fail(GE_E_BADARG, "null argument");
-  int rc = GE_OK;
+  int rc = check_state(e);
+  if (rc != GE_OK) return rc;
   if (e->P.autoreset) {
-    GeInject none = {nullptr, nullptr, nullptr, nullptr};
-    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, none, stream);
+    GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, none, e->gen, stream);
   }
   return rc;
 }
 
 extern "C" int ge_step(ge_engine *e, const int64_t *actions, void *stream) {
-  if (e && e->P.autoreset == 2) {  // next-step mode: the slots that finished in the previous step are regenerated first
+  if (!e || !actions) return fail(GE_E_BADARG, "null argument");
+  if (e->P.autoreset == 2) {  // next-step mode: the slots that finished in the previous step are regenerated first
     int rc = ge_reset_pending(e, stream);
     return rc == GE_OK ? ge_step_only(e, actions, stream) : rc;
   }
   int rc = ge_step_only(e, actions, stream);
   if (rc != GE_OK) return rc;
   return ge_reset_pending(e, stream);
+}
+
+// generation of the queue ring the next ge_reset_pending consumes (state_dict round trips between engines): set >= 0 to load it
+extern "C" int ge_queue_generation(ge_engine *e, int set) {
+  if (!e) return GE_E_BADARG;
+  if (set >= 0) { e->gen = set % GE_SEED_DEPTH; e->loaded = true; e->seeded = true; }
+  return e->gen;
 }
 
 extern "C" int ge_vectorize(ge_engine *e, float *out, void *stream) {
@@ -363,7 +473,7 @@ extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *ac
 }
 
 extern "C" int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *scratch, void *stream) {
-  if (!e || !scratch) return fail(GE_E_BADARG, "null argument");
+  if (!e) return fail(GE_E_BADARG, "null argument");
   for (int s = 0; s < n_steps; s++) {
     int rc = GE_OK;
     if (e->P.autoreset == 2) rc = ge_reset_pending(e, stream);
@@ -376,7 +486,7 @@ extern "C" int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_s
 
 extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *scratch, void *stream,
                                 double *step_ms, double *reset_ms, double *policy_ms) {
-  if (!e || !scratch) return fail(GE_E_BADARG, "null argument");
+  if (!e || (!scratch && !path64(e))) return fail(GE_E_BADARG, "null argument");
   if (!e->have_events) { for (int k = 0; k < 4; k++) if (hipEventCreate(&e->ev[k]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventCreate failed"); e->have_events = true; }
   double ts = 0, tr = 0, tp = 0;
   hipStream_t st = (hipStream_t)stream;
@@ -403,7 +513,7 @@ extern "C" int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_st
 }
 
 extern "C" int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k, int64_t *scratch, void *stream, double *burst_ms) {
-  if (!e || !scratch || !burst_ms) return fail(GE_E_BADARG, "null argument");
+  if (!e || !burst_ms) return fail(GE_E_BADARG, "null argument");
   if (!e->have_events) { for (int j = 0; j < 4; j++) if (hipEventCreate(&e->ev[j]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventCreate failed"); e->have_events = true; }
   hipStream_t st = (hipStream_t)stream;
   (void)hipEventRecord(e->ev[0], st);

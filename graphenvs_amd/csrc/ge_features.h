@@ -17,13 +17,13 @@ struct GeFctx {
   double *bc, *prx, *prn, *sinv, *diff, *clos;  // shared
 };
 
-GE_DEV GeFctx ge_carve_f(const GeParams &P) {
+GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   unsigned char *s = ge_dyn_smem();
   const GeLdsF &L = P.ldsf;
   GeFctx c;
   c.abits = (uint64_t *)(s + L.abits); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
   c.scw = (uint16_t *)(s + L.scw);
-  const int wv = ge_tid() >> 6;
+  const int wv = tid >> 6;
   c.dist = (int *)(s + L.dist) + wv * P.n;
   double *f = (double *)(s + L.f64a);
   c.bc = f; c.prx = f + P.n; c.prn = f + 2 * P.n; c.sinv = f + 3 * P.n; c.diff = f + 4 * P.n; c.clos = f + 5 * P.n;
@@ -37,12 +37,12 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P) {
 // level-synchronous Brandes pass for its own sources (s = wave, wave + waves, ...) on private scratch; per-wave
 // betweenness partial sums are combined in wave order, then wave 0 does clustering and pagerank.
 GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
-  const int tid = ge_tid(), nthreads = ge_bdim();
+  const int tid = ge_tid_fresh(), nthreads = ge_bdim();
   const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
   const int n = P.n, W = P.W, E = P.E, F = P.F, t = P.env_type;
   const ge_buffers &G = P.buf;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
-  GeFctx c = ge_carve_f(P);
+  GeFctx c = ge_carve_f(P, tid);
   // stage the slot's graph in LDS
   for (int i = tid; i < n * W; i += nthreads) c.abits[i] = G.adj_bits[nbase * W + i];
   for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
@@ -213,8 +213,15 @@ GE_DEV int *ge_f64_pre(int E, int tsp, int nblk) { return (int *)(ge_dyn_smem() 
 #define GE_F64_WALKERS (64 * GE_F64_QL)
 #define GE_F64_THREADS (GE_F64_WALKERS + 64)
 #define GE_F64_SLICE (64 / GE_F64_QL)  // nodes per lane slice
+#if GE_F64_SLICE > 32
+typedef uint64_t ge_slice_t;  // one lane per source: the lane serves every target itself
+#define GE_SLICE_CTZ(x) ge_ctz64(x)
+#else
+typedef uint32_t ge_slice_t;
+#define GE_SLICE_CTZ(x) ((int)__builtin_ctz(x))
+#endif
 GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
-  const int tid = ge_tid();
+  const int tid = ge_tid_fresh();
   const bool node_wave = tid >= GE_F64_WALKERS;
   const int lane = tid - GE_F64_WALKERS;  // node index inside the node wave
   const int n = P.n, E = P.E, F = P.F, t = P.env_type;
@@ -240,10 +247,11 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   // served in parallel while the per-source order of the float64 delta sums stays fixed.
   const int s = (tid >> 6) * (64 / GE_F64_QL) + ((tid & 63) / GE_F64_QL);
   const int q = tid & (GE_F64_QL - 1);
-  const uint32_t slice_mask = (GE_F64_SLICE == 32) ? 0xffffffffu : ((1u << (GE_F64_SLICE & 31)) - 1u);
+  const ge_slice_t slice_mask = (GE_F64_SLICE >= 32) ? (ge_slice_t)~(ge_slice_t)0 : (ge_slice_t)((1u << (GE_F64_SLICE & 31)) - 1u);
   const bool walker = !node_wave && s < n;
   bool ovf = false;
   int D = 0, reach = 1; int64_t tot = 0;
+  GE_STAMP_T0(24);
   if (walker) {
     uint64_t visited = 1ull << s, cur = visited, nxt = 0;
     if (q == 0) c.sig[s * GE_F64_SS + s] = 1;
@@ -266,14 +274,14 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
       uint64_t cand = c.abits[u] & ~visited, cand2 = two ? (c.abits[u2] & ~visited) : 0ull;
       nxt |= cand | cand2;
       // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
-      uint32_t mine = (uint32_t)(cand >> (GE_F64_SLICE * q)) & slice_mask, mine2 = (uint32_t)(cand2 >> (GE_F64_SLICE * q)) & slice_mask;
+      ge_slice_t mine = (ge_slice_t)(cand >> ((GE_F64_SLICE * q) & 63)) & slice_mask, mine2 = (ge_slice_t)(cand2 >> ((GE_F64_SLICE * q) & 63)) & slice_mask;
       while (mine | mine2) {
         if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
-          const int idx = (GE_F64_SLICE * q + (int)__builtin_ctz(mine)) * GE_F64_SS + s; mine &= mine - 1;
+          const int idx = (GE_F64_SLICE * q + GE_SLICE_CTZ(mine)) * GE_F64_SS + s; mine &= mine - 1;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su << (16 * (idx & 1)));
         }
         if (mine2) {
-          const int idx = (GE_F64_SLICE * q + (int)__builtin_ctz(mine2)) * GE_F64_SS + s; mine2 &= mine2 - 1;
+          const int idx = (GE_F64_SLICE * q + GE_SLICE_CTZ(mine2)) * GE_F64_SS + s; mine2 &= mine2 - 1;
           ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su2 << (16 * (idx & 1)));
         }
       }
@@ -324,6 +332,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   // overflowed is discarded as a whole after the last barrier (the generic kernel recomputes it).
   if (ovf) *ovf_flag = 1;
   GE_STAMP(13);
+  GE_STAMP_T0(25);
   // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
   if (walker && !ovf) {
     int d = D;
@@ -348,13 +357,14 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
       uint64_t pb = c.abits[w] & prev, pb2 = two ? (c.abits[w2] & prev) : 0ull;
       // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same
       // lane, w before w2, iteration after iteration: the float64 sum order is fixed
-      uint32_t mine = (uint32_t)(pb >> (GE_F64_SLICE * q)) & slice_mask, mine2 = (uint32_t)(pb2 >> (GE_F64_SLICE * q)) & slice_mask;
+      ge_slice_t mine = (ge_slice_t)(pb >> ((GE_F64_SLICE * q) & 63)) & slice_mask, mine2 = (ge_slice_t)(pb2 >> ((GE_F64_SLICE * q) & 63)) & slice_mask;
       while (mine | mine2) {
-        if (mine) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + (int)__builtin_ctz(mine)) * GE_F64_SD + s], coeff); mine &= mine - 1; }  // ds_add_f64
-        if (mine2) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + (int)__builtin_ctz(mine2)) * GE_F64_SD + s], coeff2); mine2 &= mine2 - 1; }
+        if (mine) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + GE_SLICE_CTZ(mine)) * GE_F64_SD + s], coeff); mine &= mine - 1; }  // ds_add_f64
+        if (mine2) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + GE_SLICE_CTZ(mine2)) * GE_F64_SD + s], coeff2); mine2 &= mine2 - 1; }
       }
     }
   }
+  GE_STAMP_T0(26);
   // closeness (wf_improved) of source s, handed to the node-per-lane phase through LDS
   if (walker && q == 0) {
     double cl = 0.0;
@@ -389,28 +399,28 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
 enum { GE_FEAT_LIST = 3 };  // slots from work_list (fallback of the fast path)
 
 // mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list
-GE_KERNEL ge_k_features(GeParams P, int mode) {
+GE_KERNEL ge_k_features(GeParams P, int mode, int gen) {
   int *pre = (int *)(ge_dyn_smem() + P.ldsf.pre);
   int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
   if (mode == GE_RESET_QUEUE) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
   const int nparts = (mode == GE_FEAT_LIST) ? 1 : P.feat_parts;
   for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
     const int item = q / nparts;
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item, gen) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
     ge_features_generic_env(P, env, q % nparts, nparts);
   }
 }
 
 // betweenness of multi-part slots: parts added in part order, then the 1/((n-1)(n-2)) rescale and the float32 cast
-GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
+GE_KERNEL ge_k_feat_combine(GeParams P, int mode, int gen) {
   int *pre = (int *)ge_dyn_smem();
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
@@ -418,7 +428,7 @@ GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
   const double scale = n > 2 ? 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)) : 1.0;
   for (int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid(); g < (int64_t)count * n; g += (int64_t)ge_gdim() * ge_bdim()) {
     const int item = (int)(g / n), v = (int)(g % n);
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : item;
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item, gen) : item;
     double acc = 0.0;
     for (int p = 0; p < nparts; p++) acc += P.buf.feat_scratch[((int64_t)env * nparts + p) * n + v];
     if (n > 2) acc *= scale;
@@ -426,17 +436,17 @@ GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
   }
 }
 
-GE_KERNEL ge_k_features64(GeParams P, int mode) {
+GE_KERNEL ge_k_features64(GeParams P, int mode, int gen) {
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   int *pre = ge_f64_pre(P.E, P.env_type == GE_TSP, nblk);
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {  // the prefix scan is one wave wide
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
     ge_sync();
     count = pre[nblk];
   }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q, gen) : q;
     ge_features64_env(P, env, pre + nblk + 1);
   }
 }

@@ -16,6 +16,10 @@
 #define GE_HOSTDEV __host__ __device__ inline
 
 GE_DEV int ge_tid() { return (int)threadIdx.x; }
+// The same value behind an opaque move.  Read at the top of the per-slot body of a persistent (slot-loop) kernel, it keeps the
+// compiler from hoisting everything it derives from the thread id -- lane masks, shuffle sources, LDS addresses -- out of the slot
+// loop, where those values stay live across the whole body and are spilled to scratch (ge_k_reset: 78 spilled VGPRs without it).
+GE_DEV int ge_tid_fresh() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 GE_DEV int ge_bid() { return (int)blockIdx.x; }
 GE_DEV int ge_bdim() { return (int)blockDim.x; }
 GE_DEV int ge_gdim() { return (int)gridDim.x; }
@@ -54,6 +58,8 @@ GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx) { return (uint32_t)__builti
 GE_DEV uint32_t ge_writelane_u32(uint32_t v, uint32_t val, int idx) { return ((int)(threadIdx.x & 63u) == idx) ? val : v; }
 // value known to be the same in every lane: keep it (and what is computed from it) on the scalar unit
 GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+GE_DEV double ge_u64_as_f64(uint64_t v) { return __longlong_as_double((long long)v); }
+GE_DEV uint64_t ge_f64_as_u64(double v) { return (uint64_t)__double_as_longlong(v); }
 GE_DEV int ge_popc64(uint64_t v) { return __popcll(v); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? (int)__builtin_clz(v) : 32; }

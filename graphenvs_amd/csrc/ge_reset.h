@@ -223,15 +223,20 @@ GE_DEV int ge_sorted_pos(const GeRctx &c, int W, int u, int v) { return c.rowptr
 
 enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
 
-struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; };
+struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; const uint32_t *seeds; };
+#ifndef GE_GNM_ROUND_CAP
+#define GE_GNM_ROUND_CAP (1 << 22)
+#endif
 
 
 // Diagnostic build only (-DGE_STAMPS, never shipped): 100 MHz timestamps of slot 0's reset phases.
 #if defined(GE_STAMPS) && !defined(GE_EMU)
 __device__ unsigned long long ge_stamp_buf[32];
 #define GE_STAMP(k) do { if (lane == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
+#define GE_STAMP_T0(k) do { if (tid == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
 #else
 #define GE_STAMP(k) do { } while (0)
+#define GE_STAMP_T0(k) do { } while (0)
 #endif
 
 
@@ -811,12 +816,12 @@ GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *m
 // The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
 // depend on the topology runs beside the python-stream graph sampling of the first wave.
 template <int ENV>
-GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, int env, int lane) {
+GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt_src, int lane) {
   constexpr int t = ENV;  // compile-time: every env type gets its own reset kernel, so none pays for the others' registers
   const int n = P.n;
   if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
   GE_STAMP(20);
-  ge_mt_load(c.mt2, P.buf.mt_state + ((int64_t)env * 2 + 1) * GE_MT_N, lane);  // pre-seeded
+  ge_mt_load(c.mt2, mt_src, lane);  // pre-seeded
   GE_STAMP(21);
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
   int nppos = GE_MT_N;
@@ -884,21 +889,31 @@ GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, cons
 }
 
 template <int ENV>
-GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, const GeInject &inj) {
+GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, int mode, const GeInject &inj, int gen, int qidx) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
   // Inside a wave only wave-level hand-offs are used; the two block barriers are the join and the end of the slot.
-  const int lane = ge_tid() & (GE_WAVE - 1);
-  const int wv = ge_tid() >> 6;
+  const int tid = ge_tid_fresh();
+  const int lane = tid & (GE_WAVE - 1);
+  const int wv = tid >> 6;
   const int n = P.n, ng = P.ng, W = P.W, m = P.m, E = P.E, F = P.F, T = P.T;
   constexpr int t = ENV;
   const bool path_like_t = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   GeRctx c = ge_carve(P);
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
+  // episode bookkeeping (written by this kernel only).  A full reset or an injection with seeds starts episode 0 with the given
+  // seed; a queued slot moves to its next episode, whose generator states sit in ring entry (episode mod GE_SEED_DEPTH); an
+  // injection without seeds leaves seed / episode alone (the episodes that follow continue the earlier sequence)
+  const bool restart = (mode == GE_RESET_ALL) || (mode == GE_RESET_INJECT && inj.seeds);
+  const int64_t episode = restart ? 0 : P.buf.episode[env] + (mode == GE_RESET_QUEUE ? 1 : 0);
+  const uint32_t seed = restart ? (mode == GE_RESET_ALL ? seeds[env] : inj.seeds[env]) : P.buf.seed[env] + (mode == GE_RESET_QUEUE ? (uint32_t)P.seed_stride : 0u);
+  const int ring = (int)(episode % GE_SEED_DEPTH);
+  const uint32_t *mt_src = P.buf.mt_state + ((int64_t)env * GE_SEED_DEPTH + ring) * 2 * GE_MT_N;
   int src = 0, dest = -1;
   int ppd_pk[5] = {-1, -1, -1, -1, -1}, ppd_dp[5] = {-1, -1, -1, -1, -1};  // perishable_product_delivery.py:72-73
+  bool gen_failed = false;
   double ppd_dt = 0.0;
   if (wv == 1) {
-    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, env, lane); ge_sync(); }
+    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, mt_src + GE_MT_N, lane); ge_sync(); }
     ge_sync();
     return;
   }
@@ -906,10 +921,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   GE_STAMP(0);
   if (mode != GE_RESET_INJECT) {
     // ---------------------------------------------------------------- topology (python stream)
-    ge_mt_load(c.mt, P.buf.mt_state + (int64_t)env * 2 * GE_MT_N, lane);  // pre-seeded (ge_k_seed)
+    ge_mt_load(c.mt, mt_src, lane);  // pre-seeded (ge_k_seed)
     GE_STAMP(1);
     int pypos = GE_MT_N;
     int ppd_attempt = 0, ppd_pos = 0;  // PerishableProductDelivery: the numpy stream is continued by this wave after the join
+    bool failed = false;               // the G(n, m) loop hit its round cap (wave-uniform)
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
     for (;;) {
       for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
@@ -927,7 +943,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         // stream order; a pair is added unless u == v or the edge exists (in the matrix, or earlier in this round).
         int cnt = 0, have_u = 0, carry_u = 0;
         const uint64_t below = (1ull << lane) - 1ull;
+        int rounds = 0;
         for (;;) {
+          // an all-zero (never seeded) or corrupted generator state draws the same pair for ever: give up loudly instead of
+          // hanging the GPU.  A healthy stream needs ~n^2 ln(n) / 64 rounds in the worst (nearly complete) case.
+          if (++rounds > GE_GNM_ROUND_CAP) { failed = true; break; }
           if (pypos >= GE_MT_N) { ge_mt_twist(c.mt, lane); pypos = 0; }
           const int p = pypos + lane;
           const bool valid = p < GE_MT_N;
@@ -992,6 +1012,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         }
       }
       ge_wave_sync();
+      if (failed) break;
       bool ok = ge_connected(c, ng, W, -1, lane);
       if (ok && t == GE_TSP) {  // tsp.py:65-71
         uint64_t deg1 = 0;
@@ -1015,6 +1036,23 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         ok = ge_ppd_place(P, c, (double *)(ge_dyn_smem() + P.lds.fw), rnd, ppd_pos, ppd_pk, ppd_dp, ppd_dt, lane);
       }
       if (ok) break;
+    }
+    if (failed) {  // flag it, and carry on with a valid graph (a path plus chords up to m edges) so that nothing downstream runs out of bounds
+      if (lane == 0) atomicOr((unsigned int *)&P.buf.work_count[1], 1u);
+      gen_failed = true;
+      for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
+      ge_wave_sync();
+      if (lane == 0) {
+        int cnt = 0;
+        for (int d = 1; d < ng && cnt < m; d++)
+          for (int u = 0; u + d < ng && cnt < m; u++) {
+            const int v = u + d;
+            c.abits[u * W + (v >> 6)] |= 1ull << (v & 63); c.abits[v * W + (u >> 6)] |= 1ull << (u & 63);
+            c.elist[cnt++] = (uint32_t)u | ((uint32_t)v << 16);
+          }
+      }
+      ge_wave_sync();
+      if (t == GE_PERISHABLE_DELIVERY) { if (ppd_attempt == 0) ge_sync(); for (int i = 0; i < P.n_dests; i++) { ppd_pk[i] = i; ppd_dp[i] = P.n_dests + i; } }
     }
   } else {
     // ---------------------------------------------------------------- injected topology
@@ -1268,8 +1306,6 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
       uint64_t codes = 0; int d = c.rowptr[v + 1] - c.rowptr[v]; if (d > 16) d = 16;
       for (int k = 0; k < d; k++) codes |= (uint64_t)(c.wsort[c.rowptr[v] + k] & 15) << (4 * k);
       G.node_rec[(nbase + v) * 2] = c.abits[v]; G.node_rec[(nbase + v) * 2 + 1] = codes;
-      const int h0 = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? 0 : src;
-      if (v == h0) { G.cur_rec[(int64_t)env * 2] = c.abits[v]; G.cur_rec[(int64_t)env * 2 + 1] = codes; }
     }
   }
   // first mask (reset() -> info['mask'])
@@ -1333,7 +1369,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
         ge_wave_sync();
       }
       for (int off = 32; off >= 1; off >>= 1) mine |= ge_shfl_u64(mine, lane ^ off);
-      if (lane == 0) G.cur_rec[(int64_t)env * 2] = want;
+      if (lane == 0) G.aux_bits[env] = want;
       if (lane == 0) acc[0] = mine;
       ge_wave_sync();
     } else
@@ -1384,11 +1420,24 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
   }
   for (int k = lane; k < T; k += GE_WAVE) G.terminals[(int64_t)env * T + k] = (t == GE_TSP) ? 0 : ((t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : ((t == GE_DISTRIBUTION_CENTER && k >= P.n_dests) ? -1 : c.perm[k]));
   if (lane == 0) {
-    G.head[env] = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? -1 : src;
-    G.cost[env] = 0.0; G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
-    G.status[env] = (mode == GE_RESET_QUEUE && P.autoreset == 2) ? 3 : 0;  // 3: regenerated at the start of this ge_step (next-step mode)
+    const uint64_t head16 = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? GE_REC_HEAD_MASK : (uint64_t)src;
+    uint64_t status = (mode == GE_RESET_QUEUE && P.autoreset == 2) ? 3ull : 0ull;  // 3: regenerated at the start of this ge_step (next-step mode)
+    if (gen_failed) status = 4ull;
+    const uint64_t aux = ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) && W == 1) ? (uint64_t)dest : 0ull;
+    // transitions since the last full reset survive a regeneration (the device policy is keyed by them)
+    const uint64_t tstep = (mode == GE_RESET_QUEUE) ? (G.slot_rec[2 * (int64_t)env + 1] >> GE_REC_TSTEP_SHIFT) : 0ull;
+    G.slot_rec[2 * (int64_t)env] = 0ull;  // cost = +0.0
+    G.slot_rec[2 * (int64_t)env + 1] = head16 | (status << GE_REC_STATUS_SHIFT) | (aux << GE_REC_AUX_SHIFT) | (tstep << GE_REC_TSTEP_SHIFT);
+    G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
+    if (mode == GE_RESET_QUEUE) G.final_heur[env] = G.heuristic[env];  // of the episode that just ended (same-step autoreset reads it after this kernel)
     G.heuristic[env] = heuristic;
-    if (mode != GE_RESET_QUEUE) { G.episode[env] = 0; G.tstep[env] = 0; G.seed[env] = seed; }
+    if (t == GE_PERISHABLE_DELIVERY && mode != GE_RESET_INJECT) G.final_cost[env] = ppd_dt;  // info['time_left'] of reset() (perishable_product_delivery.py:158), until the episode's last step overwrites it
+    G.seed[env] = seed; G.episode[env] = episode;
+    if (mode == GE_RESET_QUEUE) {  // the ring entry just consumed gets the states of the episode GE_SEED_DEPTH ahead (side stream)
+      uint32_t *job = G.seed_jobs + ((int64_t)gen * P.B + qidx) * 2;
+      job[0] = (uint32_t)env | ((uint32_t)ring << 28);
+      job[1] = seed + (uint32_t)GE_SEED_DEPTH * (uint32_t)P.seed_stride;
+    }
   }
   ge_sync();
   GE_STAMP(10);
@@ -1396,11 +1445,12 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, uint32_t seed, int mode, 
 
 // Queue mode: every step workgroup left (count, segment) in reset_count / reset_list; each reset workgroup
 // rebuilds the exclusive prefix of the counts in LDS and finds its slot by binary search.
-GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) {  // one wave; no barrier
+GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane, int gen) {  // one wave; no barrier
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  const int32_t *rc = P.buf.reset_count + (int64_t)gen * nblk;
   int carry = 0;
   for (int k0 = 0; k0 < nblk; k0 += GE_WAVE) {
-    int k = k0 + lane; int cnt = k < nblk ? P.buf.reset_count[k] : 0;
+    int k = k0 + lane; int cnt = k < nblk ? rc[k] : 0;
     int incl = ge_wave_incl_scan(cnt, lane);
     if (k < nblk) pre[k] = carry + incl - cnt;
     carry += ge_shfl_i32(incl, GE_WAVE - 1);
@@ -1408,15 +1458,10 @@ GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) {  // one
   if (lane == 0) pre[nblk] = carry;
   return carry;
 }
-GE_DEV int ge_queue_prefix(const GeParams &P, int *pre, int lane) {  // 64-thread workgroups
-  int c = ge_queue_prefix_wave(P, pre, lane);
-  ge_sync();
-  return c;
-}
-GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
+GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q, int gen) {
   int lo = 0, hi = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid; }
-  return P.buf.reset_list[lo * GE_STEP_BLOCK + (q - pre[lo])];
+  return P.buf.reset_list[(int64_t)gen * P.B + lo * GE_STEP_BLOCK + (q - pre[lo])];
 }
 
 
@@ -1426,23 +1471,32 @@ GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
 // side stream while the feature kernel of the same vector step occupies the main stream, so neither its latency nor
 // its instructions are on the step's critical path.  State layout [slot][stream][624]: the reset workgroup loads
 // its 2 x 2.5 KB with coalesced reads.
-enum { GE_SEED_GIVEN = 0, GE_SEED_GIVEN_NEXT = 1, GE_SEED_QUEUE_NEXT = 2 };
+// GE_SEED_GIVEN: ring entry 0 of every slot from seeds[] (episode 0; main stream, in front of the full reset);
+// GE_SEED_AHEAD: entries of episodes 1 .. GE_SEED_DEPTH of every slot from seed[] (side stream, after a full reset or a seeded injection);
+// GE_SEED_JOBS: the jobs the queue-mode reset kernel of generation `gen` left in seed_jobs (side stream).
+enum { GE_SEED_GIVEN = 0, GE_SEED_AHEAD = 1, GE_SEED_JOBS = 2 };
 
-GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int mode) {
+GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int mode, int gen) {
   int *pre = (int *)ge_dyn_smem();
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  int count = P.B;
-  if (mode == GE_SEED_QUEUE_NEXT) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+  int64_t count = (mode == GE_SEED_AHEAD) ? (int64_t)P.B * GE_SEED_DEPTH : P.B;
+  if (mode == GE_SEED_JOBS) {
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
     ge_sync();
     count = pre[nblk];
   }
-  const int g = ge_bid() * ge_bdim() + ge_tid();
+  const int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid();
   if (g >= count) return;
-  const int env = (mode == GE_SEED_QUEUE_NEXT) ? ge_queue_slot(P, pre, g) : g;
-  uint32_t seed = (mode == GE_SEED_QUEUE_NEXT) ? P.buf.seed[env] : seeds[env];
-  if (mode != GE_SEED_GIVEN) seed += (uint32_t)P.seed_stride;
-  uint32_t *mt = P.buf.mt_state + (int64_t)env * 2 * GE_MT_N;
+  int env, ring; uint32_t seed;
+  if (mode == GE_SEED_GIVEN) { env = (int)g; ring = 0; seed = seeds[env]; }
+  else if (mode == GE_SEED_AHEAD) {  // lanes of a wave share the episode offset, consecutive lanes take consecutive slots
+    const int j = (int)(g / P.B) + 1; env = (int)(g % P.B);
+    ring = (int)((P.buf.episode[env] + j) % GE_SEED_DEPTH); seed = P.buf.seed[env] + (uint32_t)j * (uint32_t)P.seed_stride;
+  } else {
+    const uint32_t *job = P.buf.seed_jobs + ((int64_t)gen * P.B + g) * 2;
+    env = (int)(job[0] & 0x0fffffffu); ring = (int)(job[0] >> 28); seed = job[1];
+  }
+  uint32_t *mt = P.buf.mt_state + ((int64_t)env * GE_SEED_DEPTH + ring) * 2 * GE_MT_N;
   {  // python: init_by_array([seed])
     uint32_t b = 19650218u, prev = b;
     for (int i = 1; i < GE_MT_N; i++) {
@@ -1467,24 +1521,23 @@ GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int mode) {
 }
 
 template <int ENV>
-GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj) {
+GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj, int gen) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
     ge_sync();
     count = pre[nblk];
   }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
     int env = q;
     if (mode == GE_RESET_QUEUE) {
-      if (q != ge_bid()) { if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid()); ge_sync(); }
-      env = ge_queue_slot(P, pre, q);
+      if (q != ge_bid()) { const int t2 = ge_tid_fresh(); if (t2 < GE_WAVE) ge_queue_prefix_wave(P, pre, t2, gen); ge_sync(); }
+      env = ge_queue_slot(P, pre, q, gen);
       ge_sync();  // every thread has its slot before the scratch is reused
     }
-    uint32_t seed = (mode == GE_RESET_ALL) ? seeds[env] : ((mode == GE_RESET_QUEUE) ? P.buf.seed[env] : 0u);
-    ge_reset_env<ENV>(P, env, seed, mode, inj);
+    ge_reset_env<ENV>(P, env, seeds, mode, inj, gen, q);
   }
 }

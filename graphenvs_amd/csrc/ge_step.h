@@ -21,9 +21,18 @@ GE_DEV int ge_edge_code(const GeParams &P, int env, int u, int a) {
   return P.buf.scode[(int64_t)env * P.E + r0 + ge_rank_below(row, a)];
 }
 
-// Finished slots of this workgroup go to the workgroup's own segment of reset_list, in slot order, and the
-// segment length to reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
-GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want) {
+// slot_rec: {cost as float64 bits, packed word} -- include/graphenvs.h GE_REC_*
+GE_DEV int ge_rec_head(uint64_t p) { const int h = (int)(p & GE_REC_HEAD_MASK); return h == (int)GE_REC_HEAD_MASK ? -1 : h; }
+GE_DEV int ge_rec_status(uint64_t p) { return (int)((p >> GE_REC_STATUS_SHIFT) & 0xffull); }
+GE_DEV int ge_rec_aux(uint64_t p) { return (int)((p >> GE_REC_AUX_SHIFT) & 0xffull); }
+GE_DEV uint64_t ge_rec_tstep(uint64_t p) { return p >> GE_REC_TSTEP_SHIFT; }
+GE_DEV uint64_t ge_rec_make(int head, int status, int aux, uint64_t tstep) {
+  return ((uint64_t)head & GE_REC_HEAD_MASK) | ((uint64_t)status << GE_REC_STATUS_SHIFT) | ((uint64_t)aux << GE_REC_AUX_SHIFT) | (tstep << GE_REC_TSTEP_SHIFT);
+}
+
+// Finished slots of this workgroup go to the workgroup's own segment of reset_list (generation `gen` of the queue ring), in slot
+// order, and the segment length to reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
+GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want, int gen) {
   const uint64_t b = ge_ballot(want);
   const int lane = tid & 63, wave = tid >> 6, nw = ge_bdim() >> 6;
   const int rank = ge_popc64(b & ((1ull << lane) - 1ull));
@@ -31,8 +40,8 @@ GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int ti
   ge_sync();
   int off = 0;
   for (int w = 0; w < wave; w++) off += wcnt[w];
-  if (want) P.buf.reset_list[i0 + off + rank] = i;
-  if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[ge_bid()] = tot; }
+  if (want) P.buf.reset_list[(int64_t)gen * P.B + i0 + off + rank] = i;
+  if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[(int64_t)gen * ge_gdim() + ge_bid()] = tot; }
 }
 
 #define GE_MAXW 8  // parenting >= 2 walks the residual graph per thread: node sets of up to 8 words (n <= 512)
@@ -78,8 +87,9 @@ GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
   const uint64_t *mb = P.buf.mask_bits + (int64_t)i * P.AW;
   uint32_t cnt = 0;
   for (int w = 0; w < P.AW; w++) cnt += (uint32_t)ge_popc64(mb[w]);
-  if (!cnt || P.buf.status[i] == 1) return -1;
-  uint64_t gi = (uint64_t)(P.env_index_base + i), ts = (uint64_t)P.buf.tstep[i];
+  const uint64_t packed = P.buf.slot_rec[2 * (int64_t)i + 1];
+  if (!cnt || ge_rec_status(packed) == 1 || ge_rec_status(packed) == 4) return -1;
+  uint64_t gi = (uint64_t)(P.env_index_base + i), ts = ge_rec_tstep(packed);
   uint64_t z = ge_mix64(policy_seed + gi * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
   uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
   for (int w = 0; w < P.AW; w++) {
@@ -92,7 +102,7 @@ GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
 
 // SAMPLE: the device policy is evaluated here (one launch per rollout step) and the action is also written to actions_out
 template <int ENV, bool SAMPLE>
-GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, uint64_t policy_seed) {
+GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed, int gen) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -108,20 +118,22 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
   if (i < P.B) {
     const int64_t nbase = (int64_t)i * n;
     int64_t a64;
-    if (SAMPLE) { a64 = ge_policy_pick(P, i, policy_seed); actions_out[i] = a64; } else a64 = actions[i];
-    uint8_t st = G.status[i];
+    if (SAMPLE) { a64 = ge_policy_pick(P, i, policy_seed); if (G.actions_out) G.actions_out[i] = a64; } else a64 = actions[i];
+    const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
+    double cost = ge_u64_as_f64(rec.x);
+    const int st = ge_rec_status(rec.y);
+    const int head = ge_rec_head(rec.y);
+    int head_out = head;
     double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false;
     bool cost_hidden = false;  // multicast: info['solution_cost'] stays -1 unless the episode is solved
     bool cost_lagged = false; double cost_before = 0.0;  // perishable delivery: info['solution_cost'] is read before the move
     if (st != 0 || a64 == -1) {
       // frozen slot (finished, autoreset off), a slot regenerated at the start of this step (next-step autoreset: its
       // action is ignored) or an explicit no-op: nothing moves
-      if (st == 3) G.status[i] = 0;
     } else {
       bool in_range = a64 >= 0 && a64 < (int64_t)A;
       int a = in_range ? (int)a64 : 0;
       bool mbit = in_range && ((G.mask_bits[(int64_t)i * AW + (a >> 6)] >> (a & 63)) & 1ull);
-      int head = G.head[i];
       switch (t) {
         case GE_SHORTEST_PATH:
         case GE_LONGEST_PATH: {
@@ -133,15 +145,13 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           acted = true;
           int code = nbr ? ge_edge_code(P, i, head, a) : -1;
           double wgt = (code >= 0) ? ge_wlut(code) : 0.0;  // adj[head, a] (0 when not adjacent)
-          double cost = G.cost[i];
           if (lp) { reward = wgt; cost -= wgt; } else { reward = -wgt; cost -= reward; }
-          G.cost[i] = cost;
           if (lp && (!nbr || vis_a)) {  // longest_path.py:169-173 (parenting 0 only): no state change
             done = 1; solved = 0; reward = -2.0 * n; break;
           }
           int dest = G.terminals[(int64_t)i * P.T + 1];
           if (a == dest) { done = 1; solved = 1; }
-          G.head[i] = a;
+          head_out = a;
           G.x[(nbase + a) * F + 0] = 1.f;
           uint64_t any = 0;
           uint64_t alive[GE_MAXW], R[GE_MAXW];
@@ -167,7 +177,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
         case GE_TSP: {
           const int start = 0;
           if (a64 == start && head == start) {  // tsp.py:203-211
-            acted = true; done = 1; solved = 0; reward = -(double)n; G.cost[i] = -1.0; break;
+            acted = true; done = 1; solved = 0; reward = -(double)n; cost = -1.0; break;
           }
           if (!mbit) { invalid = 1; break; }
           acted = true;
@@ -175,9 +185,9 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           double wgt = ge_wlut(code);
           if (P.spatial) wgt = G.sw64[(int64_t)i * P.E + G.row_ptr[(int64_t)i * (n + 1) + head] + ge_rank_below(G.adj_bits + (nbase + head) * W, a)];
           reward = 0.0 - wgt;
-          G.cost[i] = G.cost[i] + wgt;
+          cost = cost + wgt;
           G.x[(nbase + a) * F + 0] = 1.f;
-          G.head[i] = a;
+          head_out = a;
           int taken = G.counters[i * 2] + 1;
           G.counters[i * 2] = taken;
           if (taken == n && a == start) { done = 1; solved = 1; }
@@ -227,7 +237,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           uint16_t e = G.colw[ebase + a];
           int v = e >> 4;
           float r = -(float)ge_wlut(e & 15);
-          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;  // numpy float32 accumulator
+          float c32 = (float)cost; c32 -= r; cost = (double)c32;  // numpy float32 accumulator
           reward = (double)r;
           G.x[(nbase + v) * F + 0] = 1.f;
           uint64_t missing = 0;
@@ -259,7 +269,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           const int u = (int)(G.edge_index[ebase + a] - P.node_id_base - nbase);
           const float delay = (float)ge_wlut(e & 15);
           float r = -delay;
-          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;  // numpy float32 accumulator
+          float c32 = (float)cost; c32 -= r; cost = (double)c32;  // numpy float32 accumulator
           const double fail = -2.0 * n * P.n_dests;
           uint64_t *nbits = G.node_bits + (int64_t)i * W;
           const bool has_u = (nbits[u >> 6] >> (u & 63)) & 1ull, has_v = (nbits[v >> 6] >> (v & 63)) & 1ull;
@@ -315,7 +325,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
         }
         case GE_PERISHABLE_DELIVERY: {  // perishable_product_delivery.py:198-271
           if (!mbit) { invalid = 1; break; }
-          acted = true; cost_lagged = true; cost_before = G.cost[i];
+          acted = true; cost_lagged = true; cost_before = cost;
           const int np_ = P.n_dests;
           const int32_t *term = G.terminals + (int64_t)i * P.T;  // pickups, then drop-offs
           int pst = G.counters[i * 2];                            // 2 bits per product: 0 waiting, 1 carried, 2 delivered
@@ -329,9 +339,9 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           } else {
             const double wgt = ge_wlut(ge_edge_code(P, i, head, a));
             reward = -wgt;
-            G.cost[i] = cost_before + wgt;
+            cost = cost_before + wgt;
             G.x[(nbase + head) * F + 0] = 0.f; G.x[(nbase + a) * F + 0] = 1.f;
-            G.head[i] = a; now = a;
+            head_out = a; now = a;
             // :241 subtracts adj[head, action] after head became action -- the zero diagonal -- so TIME_LEFT never runs down
             for (int p = 0; p < np_; p++)
               if (((pst >> (2 * p)) & 3) == 1 && term[np_ + p] == a) {  // delivered
@@ -362,7 +372,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           if (!mbit) { invalid = 1; break; }
           acted = true;
           float r = -G.x[(nbase + a) * F + 0];
-          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;  // numpy float32 accumulator
+          float c32 = (float)cost; c32 -= r; cost = (double)c32;  // numpy float32 accumulator
           G.x[(nbase + a) * F + 1] = 1.f;
           uint64_t *taken = G.node_bits + (int64_t)i * W, *cov = G.cover_bits + (int64_t)i * W;
           const uint64_t *tg = G.target_bits + (int64_t)i * W, *Ra = G.range_bits + (nbase + a) * W;
@@ -400,7 +410,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           ecnt += new_edges; k += 1;
           G.counters[i * 2] = k; G.counters[i * 2 + 1] = ecnt;
           G.x[(nbase + a) * F + 0] = 1.f;
-          G.cost[i] = (double)ecnt / (double)k;
+          cost = (double)ecnt / (double)k;
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
@@ -422,7 +432,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
           if (!mbit) { invalid = 1; break; }
           acted = true;
           float r = -G.x[(nbase + a) * F + 0];
-          float c32 = (float)G.cost[i]; c32 -= r; G.cost[i] = (double)c32;
+          float c32 = (float)cost; c32 -= r; cost = (double)c32;
           reward = (double)r;
           G.x[(nbase + a) * F + 1] = 1.f;
           uint64_t any = 0;
@@ -442,31 +452,32 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
     G.terminated[i] = (uint8_t)done;
     G.invalid[i] = (uint8_t)invalid;
     G.solved[i] = (int8_t)solved;
+    int st_out = (st == 3) ? 0 : st;  // a slot regenerated at the start of this step (next-step autoreset) runs from the next step on
+    uint64_t ts = ge_rec_tstep(rec.y);
     if (acted) {
       int len = G.counters[i * 2 + (t == GE_DENSEST_SUBGRAPH || t == GE_TSP ? 0 : 1)];
       if (!(t == GE_DENSEST_SUBGRAPH || t == GE_TSP)) { len += 1; G.counters[i * 2 + 1] = len; }
-      G.tstep[i] = G.tstep[i] + 1;
+      ts = (ts + 1) & 0xffffffffull;
       if (done) {
-        G.final_cost[i] = cost_hidden ? -1.0 : (cost_lagged ? cost_before : G.cost[i]);
-        G.final_heur[i] = G.heuristic[i];
+        G.final_cost[i] = cost_hidden ? -1.0 : (cost_lagged ? cost_before : cost);
         G.final_len[i] = len;
+        if (P.autoreset != 1) G.final_heur[i] = G.heuristic[i];  // same-step autoreset: the reset kernel copies it before it overwrites `heuristic`
         if (P.autoreset) {
           want_reset = true;
-          G.seed[i] = G.seed[i] + (uint32_t)P.seed_stride;
-          G.episode[i] = G.episode[i] + 1;
-          G.status[i] = 2;
+          st_out = 2;
           if (P.autoreset == 1) wrote_mask = false;  // same-step: the reset kernel rewrites the whole slot right away
         } else {
-          G.status[i] = 1;
+          st_out = 1;
         }
       }
     }
+    if (acted || st == 3) ((ulonglong2 *)G.slot_rec)[i] = make_ulonglong2(ge_f64_as_u64(cost), ge_rec_make(head_out, st_out, ge_rec_aux(rec.y), ts));
     if (wrote_mask && !edge_mask) for (int w = 0; w < W; w++) G.mask_bits[(int64_t)i * AW + w] = stage[tid * W + w];
   }
 
   uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * W);
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, gen);  // contains the barrier
   if (edge_mask) return;  // SteinerTree updates its [B, 2m] mask incrementally above
   // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
@@ -493,17 +504,20 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, int64_t *actions_out, ui
 }
 
 // Headline fast path: ShortestPath / LongestPath(parenting 0,1) with n <= 64.  One u64 per node set.  The kernel is
-// three phases per slot: (A) every load -- the coalesced slot state, then ONE 16-byte gather for the record of the
-// chosen node; (B) the transition in registers; (C) every store.  No load is issued after the first store: vmcnt
-// counts loads and stores in order, so a late load (or a register reused at a control-flow join) would make the wave
-// wait for its stores to be acknowledged in the middle of the kernel.  Optional fused sampling of the random policy
-// (SAMPLE) so a rollout step is a single launch.
+// three phases per slot: (A) every load -- the coalesced slot state (one 16-byte record {cost, packed head / status /
+// destination / step count}, the visited set, the mask), then ONE 16-byte gather for the record of the chosen node;
+// (B) the transition in registers; (C) every store.  No load is issued after the first store: vmcnt counts loads and
+// stores in order, so a late load (or a register reused at a control-flow join) would make the wave wait for its stores
+// to be acknowledged in the middle of the kernel.  The graphs are undirected, so the weight of the move head -> a is read
+// from a's record (rank of the head among a's neighbours): the head's own record is never needed, and nothing about the
+// head is carried in the slot state beyond its index.  Optional fused sampling of the random policy (SAMPLE) so a rollout
+// step is a single launch.
 #ifndef GE_ABL
 #define GE_ABL 0  // diagnostic ablation bits (tools/step_variants.py, results are wrong by construction); 0 when shipped
 #endif
 #define GE_ON(bit) (!(GE_ABL & (bit)))  // 1 x flag, 2 bool-mask bytes, 4 gather, 8 policy, 16 state stores, 64 output stores
 template <bool SAMPLE>
-GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actions_out, uint64_t policy_seed) {
+GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t policy_seed, int gen) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -515,26 +529,20 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
   bool wrote_mask = false;
   bool want_reset = false;
   if (i < P.B) {
-    // ---- phase A, round 1: slot state (coalesced), including what only a finishing slot needs
+    // ---- phase A, round 1: slot state (coalesced)
+    const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
     const uint64_t mb = G.mask_bits[i];
-    const uint8_t st = G.status[i];
-    const int head = G.head[i];
-    const int dest = G.terminals[2 * (int64_t)i + 1];
-    const double cost0 = G.cost[i];
     const uint64_t vis0 = G.node_bits[i];
-    const int64_t ts = G.tstep[i];
-    const int len0 = G.counters[2 * i + 1];
-    const ulonglong2 crec = ((const ulonglong2 *)G.cur_rec)[i];
-    const double heur0 = G.heuristic[i];
-    const uint32_t seed0 = P.autoreset ? G.seed[i] : 0u;
-    const int64_t ep0 = P.autoreset ? G.episode[i] : 0;
+    const int head = (int)(rec.y & 63ull), st = ge_rec_status(rec.y), dest = ge_rec_aux(rec.y);
+    const uint64_t ts = ge_rec_tstep(rec.y);
+    const double cost0 = ge_u64_as_f64(rec.x);
     int64_t a64;
     if (SAMPLE) {
       const uint32_t cnt = (uint32_t)ge_popc64(mb);
-      if (!cnt || st == 1) a64 = -1;
+      if (!cnt || st == 1 || st == 4) a64 = -1;
       else if (!GE_ON(8)) a64 = ge_ctz64(mb);
       else {
-        uint64_t z = ge_mix64(policy_seed + (uint64_t)(P.env_index_base + i) * 0x9E3779B97F4A7C15ull + (uint64_t)ts * 0xD1B54A32D192ED03ull);
+        uint64_t z = ge_mix64(policy_seed + (uint64_t)(P.env_index_base + i) * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
         a64 = ge_nth_set_bit(mb, (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32));
       }
     } else {
@@ -542,16 +550,14 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
     }
     const bool in_range = a64 >= 0 && a64 < (int64_t)n;
     const int a = in_range ? (int)a64 : 0;
-    // ---- phase A, round 2: the record of the chosen node (its bit row and its packed weight codes).  The head's
-    // record travels in the slot state (cur_rec), so the reward needs no row_ptr / scode gather.
+    // ---- phase A, round 2: the record of the chosen node (its bit row and the weight codes of its 16 smallest neighbours)
     const int64_t nbase = (int64_t)i * n;
-    const uint64_t adjH = crec.x;
     const ulonglong2 arec = GE_ON(4) ? ((const ulonglong2 *)G.node_rec)[nbase + a] : make_ulonglong2(mb * 3, 0x3333333333333333ull);
-    const bool nbr = (adjH >> a) & 1ull;
-    const int rank = ge_popc64(adjH & ((1ull << a) - 1ull));
-    int code = (int)((crec.y >> (4 * (rank & 15))) & 15ull);
-    if (ge_popc64(adjH) > 16) {  // rare: the head has more than 16 neighbours -> rank-indexed byte in the scode slab
-      int pos = G.row_ptr[(int64_t)i * (n + 1) + head] + rank;
+    const bool nbr = (arec.x >> head) & 1ull;                         // adjacency is symmetric
+    const int rank = ge_popc64(arec.x & ((1ull << head) - 1ull));      // position of the head among a's neighbours
+    int code = (int)((arec.y >> (4 * (rank & 15))) & 15ull);
+    if (rank > 15) {  // rare: a has more than 16 neighbours and the head is not among the 16 smallest -> rank-indexed byte in the scode slab
+      int pos = G.row_ptr[(int64_t)i * (n + 1) + a] + rank;
       if (pos >= P.E) pos = P.E - 1;
       code = G.scode[(int64_t)i * P.E + pos];
     }
@@ -583,44 +589,36 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, int64_t *actio
     want_reset = fin && P.autoreset;
     wrote_mask = moved && !open_mask && !(want_reset && P.autoreset == 1);  // same-step: the reset kernel rewrites the slot right away
     stage[tid] = nm;
+    // a slot regenerated at the start of this step (status 3, next-step autoreset) ignored its action and runs from the next step on
+    const int st_out = fin ? (P.autoreset ? 2 : 1) : (st == 3 ? 0 : st);
+    // next-step autoreset / no autoreset: the baseline of the episode that ends here (same-step: the reset kernel copies it)
+    double heur = 0.0;
+    if (fin && P.autoreset != 1) heur = G.heuristic[i];
 
     // ---- phase C: stores only
     ge_wait_loads();
     if (GE_ON(64)) {
-      if (SAMPLE) actions_out[i] = a64;
+      if (SAMPLE && G.actions_out) G.actions_out[i] = a64;
       G.reward[i] = reward;
       G.terminated[i] = (uint8_t)done;
       G.invalid[i] = (uint8_t)invalid;
       G.solved[i] = (int8_t)solved;
     }
-    if (acted && GE_ON(16)) {
-      G.cost[i] = cost;
-      G.counters[2 * i + 1] = len0 + 1;
-      G.tstep[i] = ts + 1;
-    }
+    if ((acted || st == 3) && GE_ON(16))
+      ((ulonglong2 *)G.slot_rec)[i] = make_ulonglong2(ge_f64_as_u64(cost), ge_rec_make(moved ? a : head, st_out, dest, acted ? ((ts + 1) & 0xffffffffull) : ts));
     if (moved) {
       if (GE_ON(1)) G.x[(nbase + a) * F + 0] = 1.f;
-      if (GE_ON(16)) {
-        G.head[i] = a;
-        G.node_bits[i] = vis;
-        ((ulonglong2 *)G.cur_rec)[i] = arec;
-      }
+      if (GE_ON(16)) G.node_bits[i] = vis;
     }
     if (wrote_mask && GE_ON(16)) G.mask_bits[i] = nm;
-    if (st == 3) G.status[i] = 0;  // regenerated at the start of this step (next-step autoreset): its action was ignored
     if (fin) {
       G.final_cost[i] = cost;
-      G.final_heur[i] = heur0;
-      G.final_len[i] = len0 + 1;
-      G.status[i] = P.autoreset ? 2 : 1;
-      if (P.autoreset) {
-        G.seed[i] = seed0 + (uint32_t)P.seed_stride;
-        G.episode[i] = ep0 + 1;
-      }
+      G.final_len[i] = ge_popc64(vis0);  // every move adds one node to the visited set, which starts as {source}
+      if (P.autoreset != 1) G.final_heur[i] = heur;
     }
   }
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, gen);  // contains the barrier
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
   if (nb <= 0 || !GE_ON(2)) return;
   uint8_t *out = G.mask + (int64_t)i0 * n;
@@ -652,10 +650,10 @@ GE_KERNEL ge_k_dc_range(GeParams P, const int64_t *actions) {
   uint8_t *stk = (uint8_t *)(S + n * GE_WAVE);
   if (i >= P.B) return;
   const int64_t a64 = actions[i];
-  if (P.buf.status[i] != 0 || a64 < 0 || a64 >= (int64_t)n) return;
+  if (ge_rec_status(P.buf.slot_rec[2 * (int64_t)i + 1]) != 0 || a64 < 0 || a64 >= (int64_t)n) return;
   const int a = (int)a64;
   if (!((P.buf.mask_bits[i] >> a) & 1ull)) return;  // the step kernel will flag it invalid
-  const uint64_t have = P.buf.cur_rec[(int64_t)i * 2];
+  const uint64_t have = P.buf.aux_bits[i];
   if ((have >> a) & 1ull) return;
   const int64_t nbase = (int64_t)i * n;
   // the same label-correcting search as ge_dc_search, over node_rec: one 16-byte gather per relaxed node gives its neighbours
@@ -685,7 +683,7 @@ GE_KERNEL ge_k_dc_range(GeParams P, const int64_t *actions) {
     }
   }
   P.buf.range_bits[nbase + a] = reached;
-  P.buf.cur_rec[(int64_t)i * 2] = have | (1ull << a);
+  P.buf.aux_bits[i] = have | (1ull << a);
 }
 
 GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {

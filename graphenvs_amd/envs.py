@@ -3,10 +3,15 @@
 utils.vectorize_graph, ``info['mask']`` as a numpy bool array, done-time info keys), computed by the
 HIP engine with num_envs=1.  Meant for drop-in checks and small runs; throughput lives in
 VectorGraphEnv."""
+from collections import namedtuple
+
 import numpy as np
 import torch
 
 from .vector_env import VectorGraphEnv
+
+# gym.spaces.GraphInstance has exactly these fields (shortest_path.py:86)
+GraphInstance = namedtuple("GraphInstance", ["nodes", "edges", "edge_links"])
 
 # steiner_tree.py:137, max_independent_set.py:109, multicast_routing.py:200, distribution_center.py:150
 _F32_REWARD = ("SteinerTree-v0", "MaxIndependentSet-v0", "MulticastRouting-v0", "DistributionCenter-v0")
@@ -30,9 +35,23 @@ class GraphEnv:
         episode seed (the reference would continue the process-global streams instead)."""
         obs, info = self._v.reset(seed=None if seed is None else [int(seed)])
         self._last_cost = np.float64(0.0)
-        return self._np(obs)[0].copy(), {"mask": self._np(info["mask"])[0].copy()}
+        self._edges_taken, self._nodes_taken = [], set()  # longest_path.py:115, perishable_product_delivery.py:161, densest_subgraph.py:95
+        out = {"mask": self._np(info["mask"])[0].copy()}
+        self._graph_obs(out)
+        if self.env_id == "PerishableProductDelivery-v0":  # perishable_product_delivery.py:156-158
+            term, k = self._np(self._v.t["terminals"])[0], self._v.kwargs["n_products"]
+            out["pickups"], out["dropoffs"] = [int(v) for v in term[:k]], [int(v) for v in term[k:2 * k]]
+            out["time_left"] = float(self._np(self._v.t["final_cost"])[0])
+        return self._np(obs)[0].copy(), out
+
+    def _graph_obs(self, out):
+        """info['graph_obs'] (shortest_path.py:94-95): a copy of the slot's GraphInstance (the reference hands out its live one)"""
+        if self._v.return_graph_obs:
+            g = self._v.graph_obs()
+            out["graph_obs"] = GraphInstance(self._np(g.nodes)[0].copy(), self._np(g.edges)[0].copy(), self._np(g.edge_links)[0].copy())
 
     def step(self, action):
+        head = int(self._np(self._v.t["head"])[0])
         obs, r, term, trunc, info = self._v.step(torch.tensor([int(action)], dtype=torch.int64))
         if bool(self._np(info["invalid_action"])[0]):
             raise AssertionError(f"Mask of {action} is False!")  # shortest_path.py:113
@@ -54,6 +73,14 @@ class GraphEnv:
             cost = self._np(self._v.t["cost"])[0]
             out["solution_cost"] = np.float32(cost) if self.env_id in _F32_REWARD else np.float64(cost)
             out["heuristic_solution"] = float(self._np(self._v.t["heuristic"])[0])
+        if self.env_id in ("LongestPath-v0", "PerishableProductDelivery-v0"):  # longest_path.py:160-166, perishable_product_delivery.py:209-224
+            self._edges_taken.append((head, int(action)))
+            out["edges_taken"] = self._edges_taken
+        if self.env_id == "DensestSubgraph-v0":  # densest_subgraph.py:151,172,193
+            if int(action) != self.n_nodes - 1:
+                self._nodes_taken.add(int(action))
+            if done:
+                out["nodes_taken"] = self._nodes_taken
         return self._np(obs)[0].copy(), rew, done, False, out
 
     def close(self):

@@ -97,18 +97,43 @@ class _Space(SimpleNamespace):
     pass
 
 
+class _Slabs(dict):
+    """The engine's device slabs by name (what ge_buffers points at).  The scalar state of a slot is packed into
+    ``slot_rec`` [B, 2] = {cost as float64 bits, head | status << 16 | aux << 24 | tstep << 32} (include/graphenvs.h
+    GE_REC_*); ``t["cost"]`` / ``["head"]`` / ``["status"]`` / ``["tstep"]`` decode it on access (read-only views or copies,
+    not slabs: they are not part of state_dict())."""
+    DERIVED = ("cost", "head", "status", "tstep")
+
+    def __missing__(self, key):
+        rec = dict.__getitem__(self, "slot_rec")
+        if key == "cost":
+            return rec.view(torch.float64)[:, 0]
+        packed = rec[:, 1]
+        if key == "head":
+            h = packed & 0xFFFF
+            return torch.where(h == 0xFFFF, torch.full_like(h, -1), h).to(torch.int32)
+        if key == "status":
+            return ((packed >> 16) & 0xFF).to(torch.uint8)
+        if key == "tstep":
+            return (packed >> 32) & 0xFFFFFFFF
+        raise KeyError(key)
+
+
 class VectorGraphEnv:
     """B independent envs of one id on one GPU.  One instance per process/GPU; no global state."""
 
     def __init__(self, env_id, num_envs, n_nodes, n_edges=-1, device="cuda", autoreset=True, obs_mode="pyg",
                  env_index_base=0, seed_stride=None, strict=False, _library=None, _views=None, node_id_base=0,
-                 edge_row_stride=0, **kwargs):
+                 edge_row_stride=0, record_actions=False, copy_outputs=False, **kwargs):
         self.env_id = env_id
         self.kwargs = normalize_kwargs(env_id, n_nodes, n_edges, **kwargs)
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.obs_mode = obs_mode
         self.strict = strict
+        self.copy_outputs = bool(copy_outputs)
+        # return_graph_obs (shortest_path.py:94-95 and siblings): info['graph_obs'] = per-slot (nodes, edges, edge_links) views
+        self.return_graph_obs = bool(self.kwargs.get("return_graph_obs", False))
         # True / "same_step": a finished slot is regenerated inside the same step(); "next_step" (gymnasium's default mode): the
         # step that ends an episode returns its final observation and the NEXT step() regenerates the slot, ignoring its action;
         # False: finished slots freeze until reset()
@@ -155,19 +180,16 @@ class VectorGraphEnv:
         t["adj_bits"] = z((B * n, W), torch.int64)
         t["node_rec"] = z((B * n, 2), torch.int64) if W == 1 else None
         t["rev_edge"] = z((B * E,), torch.int32) if edge_env else None
-        t["head"] = z((B,), torch.int32)
-        t["cur_rec"] = z((B, 2), torch.int64) if W == 1 else None
+        t["slot_rec"] = z((B, 2), torch.int64)
         t["terminals"] = z((B, T), torch.int32)
         t["node_bits"] = z((B, W), torch.int64)
         t["target_bits"] = z((B, W), torch.int64)
-        t["cost"] = z((B,), torch.float64)
         t["counters"] = z((B, 2), torch.int32)
         t["seed"] = z((B,), torch.int32)
         t["episode"] = z((B,), torch.int64)
-        t["tstep"] = z((B,), torch.int64)
-        t["status"] = z((B,), torch.uint8)
         t["heuristic"] = z((B,), torch.float64)
-        t["mt_state"] = z((B, 2, 624), torch.int32)
+        t["mt_state"] = z((B, _lib.SEED_DEPTH, 2, 624), torch.int32)
+        t["aux_bits"] = z((B,), torch.int64) if (env_id == "DistributionCenter-v0" and W == 1) else None
         t["mask"] = z((B, A), torch.uint8)
         t["mask_bits"] = z((B, AW), torch.int64)
         t["reward"] = z((B,), torch.float64)
@@ -177,8 +199,9 @@ class VectorGraphEnv:
         t["final_cost"] = z((B,), torch.float64)
         t["final_heur"] = z((B,), torch.float64)
         t["final_len"] = z((B,), torch.int32)
-        t["reset_list"] = z((B,), torch.int32)
-        t["reset_count"] = z(((B + 255) // 256,), torch.int32)
+        t["reset_list"] = z((_lib.SEED_DEPTH, B), torch.int32)
+        t["reset_count"] = z((_lib.SEED_DEPTH, (B + 255) // 256), torch.int32)
+        t["seed_jobs"] = z((_lib.SEED_DEPTH, B, 2), torch.int32)
         t["work_list"] = z((B,), torch.int32)
         t["work_count"] = z((4,), torch.int32)
         t["feat_scratch"] = z((B, lay.feat_parts, n), torch.float64) if lay.feat_parts > 1 else None
@@ -186,13 +209,16 @@ class VectorGraphEnv:
         dc = env_id == "DistributionCenter-v0"
         t["range_bits"] = z((B * n, W), torch.int64) if dc else None
         t["cover_bits"] = z((B, W), torch.int64) if dc else None
+        # where the fused policy+step launches record the actions they drew (record_actions=True); off by default: 8 bytes
+        # per slot and step less to write
+        t["actions_out"] = z((B,), torch.int64) if record_actions else None
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 assert v.dtype == t[k].dtype and v.numel() >= (t[k].numel() if k != "edge_index" else 0), k
                 t[k] = v
         self.node_id_base = int(node_id_base)
-        self.t = t
-        bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in t.items()})
+        self.t = t = _Slabs(t)
+        bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in dict.items(t)})
         h = C.c_void_p()
         _lib.check(self._L, self._L.ge_create(C.byref(self.cfg), C.byref(bufs), C.byref(h)), "ge_create")
         self._h = h
@@ -245,9 +271,30 @@ class VectorGraphEnv:
     def mask(self):
         return self.t["mask"].view(torch.bool)
 
+    def graph_obs(self):
+        """info['graph_obs'] of the reference (shortest_path.py:94-95: the live GraphInstance), batched: ``nodes`` [B, n, F],
+        ``edges`` [B, E, Fe] as views of the observation slabs and ``edge_links`` [B, E, 2] local node ids."""
+        t = self.t
+        return SimpleNamespace(nodes=t["x"].view(self.num_envs, self.n, self.F),
+                               edges=t["edge_attr"].view(self.num_envs, self.E, self.Fe), edge_links=self.edge_links())
+
+    @staticmethod
+    def _copied(out):
+        def cp(v):
+            if torch.is_tensor(v):
+                return v.clone()
+            if isinstance(v, dict):
+                return {k: cp(x) for k, x in v.items()}
+            if isinstance(v, (GraphBatch, SimpleNamespace)):
+                return type(v)(**{k: cp(x) for k, x in v.__dict__.items()})
+            return v
+        return tuple(cp(v) for v in out)
+
     def _info(self, stepped):
         t = self.t
         info = {"mask": self.mask, "mask_bits": t["mask_bits"]}
+        if self.return_graph_obs:
+            info["graph_obs"] = self.graph_obs()
         if stepped:
             info.update(solved=t["solved"], solution_cost=t["final_cost"], heuristic_solution=t["final_heur"],
                         invalid_action=t["invalid"].view(torch.bool), episode_length=t["final_len"])
@@ -276,20 +323,26 @@ class VectorGraphEnv:
         self._seeds_keepalive = seeds
         _lib.check(self._L, self._L.ge_reset(self._h, seeds.data_ptr(), self._stream()), "ge_reset")
         self._was_reset = True
-        return self._obs(), self._info(False)
+        out = (self._obs(), self._info(False))
+        return self._copied(out) if self.copy_outputs else out
 
     def step(self, actions):
+        """One transition of every slot.  The returned reward / terminated / info tensors (and the observation) ALIAS engine
+        slabs that the next step() overwrites -- unlike a gymnasium VectorEnv, which returns fresh arrays: ``.clone()`` what a
+        rollout buffer keeps across steps (or construct the env with ``copy_outputs=True``)."""
         if not torch.is_tensor(actions):
             actions = torch.as_tensor(np.asarray(actions, dtype=np.int64))
         actions = actions.to(device=self.device, dtype=torch.int64).contiguous()
         assert actions.shape == (self.num_envs,)
+        assert self._was_reset, "call reset() (or inject_state()) before step()"
         self._act_keepalive = actions
         _lib.check(self._L, self._L.ge_step(self._h, actions.data_ptr(), self._stream()), "ge_step")
         t = self.t
         if self.strict and bool(t["invalid"].any()):
             bad = torch.nonzero(t["invalid"]).flatten().tolist()
             raise AssertionError(f"invalid action in slots {bad[:8]} (the reference asserts here)")
-        return self._obs(), t["reward"], t["terminated"].view(torch.bool), self._truncated, self._info(True)
+        out = (self._obs(), t["reward"], t["terminated"].view(torch.bool), self._truncated, self._info(True))
+        return self._copied(out) if self.copy_outputs else out
 
     # ------------------------------------------------------------------ extras
     def sample_random_actions(self, policy_seed=0, out=None):
@@ -326,14 +379,22 @@ class VectorGraphEnv:
                                                         self._stream(), C.byref(ms)), "ge_timed_step_burst")
         return ms.value * 1e3 / k
 
-    def inject_state(self, links, wcode, x, terminals=None):
+    def inject_state(self, links, wcode, x, terminals=None, seeds=None):
         """Parity path: load post-reset states produced elsewhere (links [B,E,2] local ids, wcode [B,E] in
-        {3..10}, x [B,n,F], terminals [B,T])."""
+        {3..10}, x [B,n,F], terminals [B,T]).  ``seeds`` [B] (optional): the seed each injected episode is taken to have;
+        autoreset then continues with reset(seed + seed_stride), ... -- required on an engine with autoreset that was
+        never reset()."""
         dev = self.device
         links_np, wcode_np = np.asarray(links), np.asarray(wcode)
         # the kernel indexes LDS rows with these: refuse what the reference could never produce
         assert links_np.min() >= 0 and links_np.max() < self.n, "edge_links must hold local node ids in [0, n_nodes)"
         assert wcode_np.min() >= 3 and wcode_np.max() <= 10, "weight codes are k with weight k/10.0, k in 3..10"
+        # the graphs are undirected: the step kernels read the weight of u -> v from either end
+        Bn = links_np.shape[0]
+        wmat = np.zeros((Bn, self.n, self.n), dtype=np.uint8)
+        bi = np.arange(Bn)[:, None]
+        wmat[bi, links_np[..., 0], links_np[..., 1]] = wcode_np
+        assert np.array_equal(wmat, wmat.transpose(0, 2, 1)), "edge weights must be symmetric (weight(u,v) == weight(v,u))"
         links = torch.as_tensor(links_np, dtype=torch.int64).to(dev).contiguous()
         wcode = torch.as_tensor(np.asarray(wcode), dtype=torch.uint8).to(dev).contiguous()
         x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dev).contiguous()
@@ -345,9 +406,15 @@ class VectorGraphEnv:
             assert term.shape == (self.num_envs, self.T)
         assert links.shape == (self.num_envs, self.E, 2) and wcode.shape == (self.num_envs, self.E)
         assert x.shape == (self.num_envs, self.n, self.F)
-        self._inj_keepalive = (links, wcode, x, term)
+        sd = None
+        if seeds is not None:
+            sn = np.asarray(seeds.cpu() if torch.is_tensor(seeds) else seeds, dtype=np.int64).reshape(self.num_envs)
+            assert ((sn >= 0) & (sn < (1 << 32))).all(), "seeds must be in [0, 2**32)"
+            sd = torch.from_numpy(sn.astype(np.uint32).view(np.int32)).to(dev)
+        self._inj_keepalive = (links, wcode, x, term, sd)
         _lib.check(self._L, self._L.ge_inject_state(self._h, links.data_ptr(), wcode.data_ptr(), x.data_ptr(),
-                                                    term.data_ptr() if term is not None else None, self._stream()),
+                                                    term.data_ptr() if term is not None else None,
+                                                    sd.data_ptr() if sd is not None else None, self._stream()),
                    "ge_inject_state")
         self._was_reset = True
         return self._obs(), self._info(False)
@@ -358,15 +425,28 @@ class VectorGraphEnv:
             torch.cuda.synchronize(self.device)
 
     def state_dict(self):
-        """Snapshot of every engine slab (the whole state of the batch, generator states included)."""
+        """Snapshot of every engine slab (the whole state of the batch, generator states included) plus the one host-side
+        number of the engine: the generation of its reset-queue ring."""
         self._quiesce()
-        return {k: v.clone() for k, v in self.t.items() if v is not None}
+        sd = {k: v.clone() for k, v in dict.items(self.t) if v is not None}
+        sd["_queue_generation"] = int(self._L.ge_queue_generation(self._h, -1))
+        return sd
 
     def load_state_dict(self, sd):
         self._quiesce()
         for k, v in sd.items():
-            self.t[k].copy_(v)
+            if k != "_queue_generation":
+                dict.__getitem__(self.t, k).copy_(v)
+        self._L.ge_queue_generation(self._h, int(sd["_queue_generation"]))
+        self._was_reset = True
         self._quiesce()
+
+    def check_device_errors(self):
+        """Raise if a kernel flagged an error it could not report otherwise (synchronises): bit 0 = a G(n, m) rejection loop
+        hit its round cap (generator state never seeded or corrupted); the slot's status is 4 and it stays frozen."""
+        flags = int(self.t["work_count"][1].item())
+        if flags:
+            raise RuntimeError(f"graphenvs_amd: device error flags {flags:#x} (bit 0: graph generation gave up -- unseeded generator state?)")
 
     def edge_links(self):
         """[B, E, 2] local node ids (GraphInstance.edge_links of every slot)."""

@@ -10,7 +10,9 @@
  *    (the Python host allocates them with torch); the library never allocates device memory;
  *  - every launch goes to the hipStream_t passed as `stream` (void*, NULL = default stream), except the
  *    MT19937 pre-seeding kernel, which runs on a side stream the engine owns and is ordered against
- *    `stream` with events; no call synchronises the stream or the device;
+ *    `stream` with events; no call synchronises the stream or the device.  The side stream only ever reads
+ *    and writes engine slabs (seed_jobs, reset_count, mt_state): a pointer the caller passes to a call
+ *    (seeds, actions, ...) is consumed on `stream` only and may be reused once `stream` has passed the call;
  *  - int return code: GE_OK or a negative GE_E_* value; no exceptions cross the ABI;
  *  - gfx950 only.
  */
@@ -22,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 1
+#define GE_ABI_VERSION 2
 
 /* env ids of graph_envs/__init__.py:9-56 that are on the hot path */
 enum {
@@ -42,8 +44,18 @@ enum {
   GE_E_BADARG = -1,      /* invalid config / null pointer */
   GE_E_UNSUPPORTED = -2, /* valid in the reference but not built yet */
   GE_E_LAUNCH = -3,      /* HIP launch/runtime error (hipGetLastError) */
-  GE_E_TOOBIG = -4       /* per-env graph does not fit the LDS-resident reset kernel */
+  GE_E_TOOBIG = -4,      /* per-env graph does not fit the LDS-resident reset kernel */
+  GE_E_STATE = -5        /* call order: the engine holds no episode yet (ge_reset / ge_inject_state first), or autoreset needs
+                            generator states that were never seeded (ge_reset, or ge_inject_state with seeds) */
 };
+
+/* slot_rec[2*i + 1]: packed scalar state of slot i */
+#define GE_REC_HEAD_MASK   0xffffull        /* bits 0-15: path head / TSP head / delivery vehicle; 0xffff = none */
+#define GE_REC_STATUS_SHIFT 16              /* bits 16-23: 0 running, 1 finished (autoreset off), 2 needs reset,
+                                               3 regenerated in this ge_step (next-step mode), 4 generation failed (see work_count[1]) */
+#define GE_REC_AUX_SHIFT   24               /* bits 24-31: ShortestPath / LongestPath with n <= 64: the destination node */
+#define GE_REC_TSTEP_SHIFT 32               /* bits 32-63: transitions executed by the slot since the last ge_reset (mod 2^32) */
+#define GE_SEED_DEPTH 3                     /* generator states kept per slot: the next GE_SEED_DEPTH episodes are pre-seeded */
 
 /* Constructor kwargs of the reference env classes, plus batch geometry.
  * shortest_path.py:23, longest_path.py:26, steiner_tree.py:26, tsp.py:22,
@@ -98,23 +110,25 @@ typedef struct {
   double *sw64;         /* [Ne]      spatial TSP only: float64 edge weights in ascending-neighbour order (else NULL) */
   uint64_t *adj_bits;   /* [Nn, W]   adjacency bit rows                                     */
   uint64_t *node_rec;   /* [Nn, 2]   n <= 64 only: {bit row, weight codes of the 16 smallest neighbours as nibbles}:
-                                     everything a step needs about a node in one 16-byte gather (else NULL) */
+                                     everything a step needs about a node in one 16-byte gather (else NULL).  The graphs are
+                                     undirected (weight(u,v) == weight(v,u)): the n <= 64 path kernel reads the weight of the
+                                     move head -> a from a's record, so the head's record is never fetched */
   int32_t *rev_edge;    /* [Ne]      SteinerTree, MulticastRouting parenting 2: local index of the reverse directed edge (else NULL) */
   /* --- per-slot dynamic state */
-  int32_t *head;        /* [B]  path head / TSP head                                        */
-  uint64_t *cur_rec;    /* [B, 2] node_rec of the head, carried in the coalesced slot state (else NULL) */
+  uint64_t *slot_rec;   /* [B, 2] {solution_cost accumulator as float64 bits (f32 semantics for Steiner/MIS), packed word GE_REC_*}:
+                                 the scalar state of a slot in ONE coalesced 16-byte record */
   int32_t *terminals;   /* [B, T] T = max(2, n_dests+1): src, dest(s)                        */
   uint64_t *node_bits;  /* [B, W] visited / in-tree / taken set                              */
   uint64_t *target_bits;/* [B, W] SteinerTree: targets                                       */
-  double *cost;         /* [B]  solution_cost accumulator (f32 semantics for Steiner/MIS)    */
-  int32_t *counters;    /* [B, 2] taken count, edge count (Densest) / steps in episode       */
-  uint32_t *seed;       /* [B]  seed of the slot's current episode                           */
-  int64_t *episode;     /* [B]  episode index k of the slot                                  */
-  int64_t *tstep;       /* [B]  transitions executed by the slot since creation              */
-  uint8_t *status;      /* [B]  0 = running, 1 = finished (autoreset off), 2 = needs reset, 3 = regenerated in this ge_step (next-step mode) */
+  int32_t *counters;    /* [B, 2] taken count, edge count (Densest) / steps in episode (unused by the n <= 64 path kernel:
+                                 an episode's length is the size of its visited set)          */
+  uint32_t *seed;       /* [B]  seed of the slot's current episode (written by the reset kernel only) */
+  int64_t *episode;     /* [B]  episode index k of the slot (written by the reset kernel only) */
   double *heuristic;    /* [B]  heuristic_solution of the current episode (is_eval_env)      */
-  uint32_t *mt_state;   /* [B, 2, 624] MT19937 states (python stream, numpy stream) already seeded for the slot's NEXT
-                                 reset: seeded one lane per slot by a helper kernel on the engine's side stream */
+  uint32_t *mt_state;   /* [B, GE_SEED_DEPTH, 2, 624] MT19937 states (python stream, numpy stream) of the slot's next GE_SEED_DEPTH
+                                 episodes, episode e in ring entry e mod GE_SEED_DEPTH: seeded one lane per slot by a helper
+                                 kernel on the engine's side stream, GE_SEED_DEPTH episodes ahead of their use */
+  uint64_t *aux_bits;   /* [B]  DistributionCenter with n <= 64: which rows of range_bits exist (else NULL) */
   /* --- outputs of the last step / reset */
   uint8_t *mask;        /* [B, A] info['mask'] as bool bytes                                 */
   uint64_t *mask_bits;  /* [B, ceil(A/64)] same, packed                                      */
@@ -123,13 +137,18 @@ typedef struct {
   uint8_t *invalid;     /* [B]  1 where the reference would have raised AssertionError       */
   int8_t *solved;       /* [B]  info['solved']: -1 absent, 0/1                               */
   double *final_cost;   /* [B]  info['solution_cost'] where terminated                       */
-  double *final_heur;   /* [B]  info['heuristic_solution'] where terminated                  */
+  double *final_heur;   /* [B]  info['heuristic_solution'] where terminated (same-step autoreset: copied by the reset kernel
+                                 before it overwrites `heuristic`)                             */
   int32_t *final_len;   /* [B]  episode length where terminated                              */
-  /* --- reset work queue */
-  int32_t *reset_list;  /* [B]  step workgroup g (256 slots) lists its finished slots at [256g, 256g+count) */
-  int32_t *reset_count; /* [ceil(B/256)] finished slots per step workgroup, rewritten by every step    */
+  /* --- reset work queue (ring of GE_SEED_DEPTH generations, generation = ge_step count mod GE_SEED_DEPTH: the side stream
+   *     may still be reading generation g while the next steps fill g+1, g+2) */
+  int32_t *reset_list;  /* [GE_SEED_DEPTH, B]  step workgroup g (256 slots) lists its finished slots at [256g, 256g+count) */
+  int32_t *reset_count; /* [GE_SEED_DEPTH, ceil(B/256)] finished slots per step workgroup            */
+  uint32_t *seed_jobs;  /* [GE_SEED_DEPTH, B, 2] per regenerated slot, in queue order: {slot | ring entry << 28, seed} of the generator
+                                 state the side stream has to produce next (written by the reset kernel) */
   int32_t *work_list;   /* [B]  slots the n<=64 feature fast path hands to the generic feature kernel  */
-  int32_t *work_count;  /* [4]  [0] = entries in work_list                                             */
+  int32_t *work_count;  /* [4]  [0] = entries in work_list; [1] = device error flags (bit 0: a G(n,m) rejection loop hit its
+                                 round cap -- unseeded or corrupted generator state; the slot's status is 4) */
   double *feat_scratch; /* [B, parts, n] n > 64 only: betweenness partial sums when several workgroups share a slot
                                  (parts = ge_layout.feat_parts; NULL when parts == 1) */
   int32_t *node_aux;    /* [B, n] MulticastRouting parenting >= 3: the one selectable edge into each node outside the tree
@@ -137,11 +156,17 @@ typedef struct {
   uint64_t *range_bits; /* [B, n, W] DistributionCenter: nodes within max_distance of each node, from that node as the
                                  Dijkstra source (distribution_center.py:25-26); else NULL */
   uint64_t *cover_bits; /* [B, W] DistributionCenter: covered nodes; else NULL */
+  int64_t *actions_out; /* [B]  optional (may be NULL): where the fused policy+step launches of ge_random_rollout / ge_timed_*
+                                 record the actions they drew; NULL = not recorded (8 bytes per slot and step less to write) */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;
 
 int ge_abi_version(void);
+
+/* hash of the HIP sources + this header the binary was compiled from (-DGE_SOURCE_HASH, set by graphenvs_amd/_lib.py build()):
+ * the host compares it with the sources on disk and refuses (or rebuilds) a stale binary */
+const char *ge_source_hash(void);
 
 /* sizes for a config; replaces the observation_space/action_space arithmetic of the
  * constructors (shortest_path.py:40-42, steiner_tree.py:43-45, tsp.py:41-42). */
@@ -152,7 +177,7 @@ int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out);
 int ge_destroy(ge_engine *e);
 
 /* env.reset(seed=s) for every slot (shortest_path.py:47-98 and the five siblings):
- * seeds [B] uint32 on device = first-episode seed per slot; sets episode = 0.
+ * seeds [B] uint32 on device = first-episode seed per slot (read on `stream` only); sets episode = 0.
  * Runs graph sampling, weights (a8), terminals (a9), structural features (a6),
  * baselines (a16), first mask; fills the observation slabs. */
 int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream);
@@ -168,9 +193,18 @@ int ge_reset_pending(ge_engine *e, void *stream);
 
 /* Parity path: load a post-reset state produced elsewhere instead of sampling it
  * (SURVEY 7 "injecting the oracle's post-reset state").  links [B,E,2] int64 local node ids in
- * edge_links order, wcode [B,E] uint8 weight codes, x [B,n,F] float32, terminals [B,T] int32. */
+ * edge_links order, wcode [B,E] uint8 weight codes (symmetric: the code of u->v equals the code of v->u),
+ * x [B,n,F] float32, terminals [B,T] int32.  seeds [B] uint32 or NULL: the seed each injected episode is taken to have
+ * -- sets seed[] and episode = 0 and pre-seeds the generator states of the following episodes, so that autoreset continues
+ * with reset(seed + seed_stride), ...; with NULL the engine must have been seeded by an earlier ge_reset (or run with
+ * autoreset off), and the episodes that follow continue that earlier sequence. */
 int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
-                    const int32_t *terminals, void *stream);
+                    const int32_t *terminals, const uint32_t *seeds, void *stream);
+
+/* Checkpointing: the engine's state is its slabs plus ONE host-side number, the generation of the queue ring the next
+ * ge_reset_pending consumes.  set < 0: return it; set >= 0: load it (after the caller has restored every slab of a
+ * snapshot taken from an engine that had been reset; marks the engine as holding an episode and seeded). */
+int ge_queue_generation(ge_engine *e, int set);
 
 /* utils.vectorize_graph for the whole batch (utils.py:87-88): out [B, obs_len] float32. */
 int ge_vectorize(ge_engine *e, float *out, void *stream);
@@ -179,7 +213,8 @@ int ge_vectorize(ge_engine *e, float *out, void *stream);
  * restated in oracle/ge_oracle.c oge_policy_pick).  actions [B] int64; -1 where the mask is empty. */
 int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream);
 
-/* n_steps x (sample, step[, autoreset]) without host involvement between launches. */
+/* n_steps x (sample, step[, autoreset]) without host involvement between launches.  actions_scratch [B] int64 is
+ * only needed by env types without a fused policy+step kernel (it may be NULL otherwise). */
 int ge_random_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_t *actions_scratch,
                       void *stream);
 

@@ -157,6 +157,7 @@ inline void wave_leave(int g) { (void)g; }
 }  // namespace ge_emu
 
 GE_DEV int ge_tid() { return ge_emu::blk().cur; }
+GE_DEV int ge_tid_fresh() { return ge_emu::blk().cur; }
 GE_DEV int ge_bid() { return ge_emu::blk().bid; }
 GE_DEV int ge_bdim() { return ge_emu::blk().nthreads; }
 GE_DEV int ge_gdim() { return ge_emu::blk().gdim; }
@@ -206,6 +207,8 @@ GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 GE_DEV void ge_lds_add_f64(double *p, double v) { *p += v; }
 GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return v; }
 GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx);
+GE_DEV double ge_u64_as_f64(uint64_t v) { double d; memcpy(&d, &v, 8); return d; }
+GE_DEV uint64_t ge_f64_as_u64(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
 GE_DEV int ge_popc64(uint64_t v) { return __builtin_popcountll(v); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }

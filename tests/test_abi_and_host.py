@@ -22,7 +22,21 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ge_abi_version() == 1
+    assert lib.ge_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GE_ABI_VERSION (\d+)", header).group(1))
+
+
+def test_binary_carries_the_hash_of_its_sources(tmp_path):
+    """the .so embeds the hash of csrc/* + the header; build() reuses a binary only when that hash equals
+    the sources on disk, and load() refuses / rebuilds a stale one instead of mapping whatever file is there."""
+    _lib.build()
+    want = _lib.source_hash()
+    assert _lib.built_hash() == want and _lib.load().ge_source_hash().decode() == want
+    _lib.build()
+    assert _lib.last_build == "reused"
+    stale = tmp_path / "libstale.so"
+    data = open(_lib.LIB_PATH, "rb").read()
+    stale.write_bytes(data.replace(b"GE_SOURCE_HASH=" + want.encode(), b"GE_SOURCE_HASH=" + b"0" * 32))
+    assert _lib.built_hash(str(stale)) == "0" * 32 != want
 
 
 def test_struct_sizes_match_header_field_counts():

@@ -116,7 +116,7 @@ def test_invalid_actions_are_flagged_and_leave_state_untouched():
     ge = _ge()
     env = ge.make_vec("ShortestPath-v0", 8, n_nodes=10, n_edges=20, autoreset=False, obs_mode="flat")
     obs, info = env.reset(seed=3)
-    before = {k: v.clone() for k, v in env.state_dict().items() if k in ("x", "head", "node_bits", "cost", "mask", "mask_bits")}
+    before = {k: v.clone() for k, v in env.state_dict().items() if k in ("x", "slot_rec", "node_bits", "mask", "mask_bits")}
     mask = info["mask"].cpu().numpy()
     bad = torch.tensor([int(np.nonzero(~mask[i])[0][0]) for i in range(8)], device="cuda")
     bad[1] = 10; bad[2] = -5; bad[3] = -1  # out of range, negative, explicit no-op

@@ -13,15 +13,16 @@ from graphenvs_amd import _lib  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "libgraphenvs_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                       "-DGE_STAMPS", "-I" + _lib.CSRC, os.path.join(_lib.CSRC, "ge_api.hip"), "-o", out])
+extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+subprocess.check_call(_lib.compile_command(out, extra=["-DGE_STAMPS"] + extra))
 L = _lib.bind(C.CDLL(out))
 L.ge_debug_read_stamps.argtypes = [C.c_void_p]
 import graphenvs_amd as ge  # noqa: E402
 
-names = {0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B load+zero", 12: "B bfs forward", 13: "B backward", 14: "B bc/clos/clust", 15: "B pagerank", 16: "B write", 20: "A1 state load", 21: "A1 draws", 22: "A1 terminals"}
+print("flags:", extra)
+names = {24: "B walker forward", 25: "B walker backward", 0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B load+zero", 12: "B node wave: clustering+pagerank", 13: "B node wave waits for the walkers", 14: "B betweenness reduction", 15: "B pagerank", 16: "B write", 20: "A1 state load", 21: "A1 draws", 22: "A1 terminals"}
 cfgs = [("ShortestPath-v0", dict(n_nodes=64, n_edges=192), [1, 4096, 65536])]
-if len(sys.argv) > 1 and sys.argv[1] == "all":
+if "all" in sys.argv[1:]:
     cfgs += [("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), [1, 2048]),
              ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), [1, 1024])]
 for env_id, kw, Bs in cfgs:
@@ -36,5 +37,6 @@ for env_id, kw, Bs in cfgs:
         print(f"{env_id} {kw} B={B}:")
         for k, nm in names.items():
             nxt = k + 1 if k != 6 else 9
+            if k == 14: nxt = 16
             if ts[k] and ts[nxt]:
                 print(f"    {nm:22s} {(ts[nxt]-ts[k])/100:9.1f} us")

@@ -11,8 +11,7 @@ for vi, spec in enumerate(sys.argv[1:] or [""]):
     flags = spec.split()
     out = os.path.join(ROOT, "gpurun_out", f"libge_variant_{os.getpid()}_{vi}.so")  # a new path per variant: dlopen caches by path
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", *flags,
-                           "-I" + _lib.CSRC, os.path.join(_lib.CSRC, "ge_api.hip"), "-o", out])
+    subprocess.check_call(_lib.compile_command(out, extra=flags))
     L = _lib.bind(C.CDLL(out))
     B = int(os.environ.get("GE_B", 65536))
     env = ge.VectorGraphEnv("ShortestPath-v0", B, 64, 192, device="cuda", _library=L)

@@ -10,8 +10,7 @@ flags = sys.argv[1].split()
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 out = os.path.join(ROOT, "gpurun_out", "libge_variant.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", *flags,
-                       "-I" + _lib.CSRC, os.path.join(_lib.CSRC, "ge_api.hip"), "-o", out])
+subprocess.check_call(_lib.compile_command(out, extra=flags))
 L = _lib.bind(C.CDLL(out))
 env = ge.VectorGraphEnv("ShortestPath-v0", 65536, 64, 192, device="cuda", _library=L)
 env.reset(seed=0); env.random_rollout(10, 1); torch.cuda.synchronize()

@@ -10,8 +10,7 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for spec in sys.argv[1:]:
     name, _, flags = spec.partition("=")
     out = os.path.join(ROOT, "gpurun_out", f"libge_var_{name}.so")
-    subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           *flags.split(), "-I" + _lib.CSRC, os.path.join(_lib.CSRC, "ge_api.hip"), "-o", out])
+    subprocess.check_call(_lib.compile_command(out, extra=flags.split()))
     L = _lib.bind(C.CDLL(out))
     res = []
     for B in (768, 2560):
