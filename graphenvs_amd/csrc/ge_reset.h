@@ -816,9 +816,10 @@ GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *m
 // The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
 // depend on the topology runs beside the python-stream graph sampling of the first wave.
 template <int ENV>
-GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt_src, int lane) {
+GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt_src, int lane, int env) {
   constexpr int t = ENV;  // compile-time: every env type gets its own reset kernel, so none pays for the others' registers
   const int n = P.n;
+  (void)env;  // only the diagnostic stamps name the slot
   if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
   GE_STAMP(20);
   ge_mt_load(c.mt2, mt_src, lane);  // pre-seeded
@@ -913,7 +914,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   bool gen_failed = false;
   double ppd_dt = 0.0;
   if (wv == 1) {
-    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, mt_src + GE_MT_N, lane); ge_sync(); }
+    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, mt_src + GE_MT_N, lane, env); ge_sync(); }
     ge_sync();
     return;
   }
@@ -1431,7 +1432,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
     if (mode == GE_RESET_QUEUE) G.final_heur[env] = G.heuristic[env];  // of the episode that just ended (same-step autoreset reads it after this kernel)
     G.heuristic[env] = heuristic;
-    if (t == GE_PERISHABLE_DELIVERY && mode != GE_RESET_INJECT) G.final_cost[env] = ppd_dt;  // info['time_left'] of reset() (perishable_product_delivery.py:158), until the episode's last step overwrites it
+    if (t == GE_PERISHABLE_DELIVERY && mode != GE_RESET_INJECT) G.target_bits[(int64_t)env * W] = ge_f64_as_u64(ppd_dt);  // info['time_left'] of reset() (perishable_product_delivery.py:158) as float64 bits: this env has no target set
     G.seed[env] = seed; G.episode[env] = episode;
     if (mode == GE_RESET_QUEUE) {  // the ring entry just consumed gets the states of the episode GE_SEED_DEPTH ahead (side stream)
       uint32_t *job = G.seed_jobs + ((int64_t)gen * P.B + qidx) * 2;

@@ -41,7 +41,7 @@ class GraphEnv:
         if self.env_id == "PerishableProductDelivery-v0":  # perishable_product_delivery.py:156-158
             term, k = self._np(self._v.t["terminals"])[0], self._v.kwargs["n_products"]
             out["pickups"], out["dropoffs"] = [int(v) for v in term[:k]], [int(v) for v in term[k:2 * k]]
-            out["time_left"] = float(self._np(self._v.t["final_cost"])[0])
+            out["time_left"] = float(self._np(self._v.t["target_bits"])[0].view(np.float64)[0])
         return self._np(obs)[0].copy(), out
 
     def _graph_obs(self, out):

@@ -11,6 +11,7 @@ import golden_util as gu
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 import build_emu  # noqa: E402
+import host_checks as hc  # noqa: E402
 
 import graphenvs_amd as ge  # noqa: E402
 
@@ -145,86 +146,18 @@ def test_emulated_next_step_autoreset(emu):
 
 
 def test_emulated_call_order_is_guarded(emu):
-    """stepping an engine whose generator states were never seeded must be refused, not hang the device."""
-    import torch
-    env = ge.VectorGraphEnv("TSP-v0", 3, 6, 12, device="cpu", _library=emu, parenting=1)
-    with pytest.raises(AssertionError):
-        env.step(torch.zeros(3, dtype=torch.int64))
-    env._was_reset = True  # past the host-side assert: the C ABI refuses as well
-    with pytest.raises(RuntimeError, match="ge_reset"):
-        env.step(torch.zeros(3, dtype=torch.int64))
-    with pytest.raises(RuntimeError, match="ge_reset"):
-        env.random_rollout(1)
+    hc.check_call_order(ge, "cpu", emu)
 
 
 @pytest.mark.parametrize("mode", [True, "next_step"])
 def test_emulated_inject_with_seeds_then_autoreset(emu, mode):
-    """inject_state as the first call on an engine with autoreset: refused without seeds; with seeds the episodes that follow
-    are reset(seed + k * stride), and seed[] / episode[] say so."""
     import oracle
-    from inject_check import wcodes_from_edges
-    import torch
-    B, n, m, stride = 5, 8, 14, 100
-    kw = dict(n_nodes=n, n_edges=m)
-    refs = [oracle.OracleEnv("ShortestPath-v0", **kw) for _ in range(B)]
-    seeds = [40 + 3 * i for i in range(B)]
-    for r, sd in zip(refs, seeds):
-        r.reset(seed=sd)
-    env = ge.VectorGraphEnv("ShortestPath-v0", B, device="cpu", _library=emu, obs_mode="flat", autoreset=mode, seed_stride=stride, **kw)
-    links = np.stack([r.edge_links() for r in refs]); wcode = np.stack([wcodes_from_edges(r.edges()[:, 0]) for r in refs])
-    x = np.stack([r.nodes() for r in refs]); terms = np.stack([r.terminals() for r in refs]).astype(np.int32)
-    with pytest.raises(RuntimeError, match="seed"):
-        env.inject_state(links, wcode, x, terms)
-    obs, info = env.inject_state(links, wcode, x, terms, seeds=seeds)
-    assert np.array_equal(obs.numpy(), np.stack([r.obs() for r in refs]))
-    pending, resets, tcount = [False] * B, 0, [0] * B
-    for k in range(30):
-        a = env.sample_random_actions(policy_seed=2).clone()
-        obs, rew, term, _, info = env.step(a)
-        for i, r in enumerate(refs):
-            if pending[i]:  # next-step mode: regenerated now, action ignored
-                seeds[i] += stride; r.reset(seed=seeds[i]); pending[i] = False; resets += 1
-                assert float(rew[i]) == 0 and not bool(term[i])
-                continue
-            _, rr, dd, _, _ = r.step(int(a[i])); tcount[i] += 1
-            assert rr == float(rew[i]) and dd == bool(term[i]), (k, i)
-            if dd and mode is True:
-                seeds[i] += stride; r.reset(seed=seeds[i]); resets += 1
-            elif dd:
-                pending[i] = True
-        assert np.array_equal(env.flat_obs().numpy(), np.stack([r.obs() for r in refs])), k
-        assert np.array_equal(info["mask"].numpy(), np.stack([r.mask() for r in refs])), k
-    assert resets > B
-    assert env.t["seed"].numpy().view(np.uint32).tolist() == seeds
-    env.check_device_errors()
+    hc.check_inject_seeds_autoreset(ge, oracle, "cpu", emu, mode)
 
 
 def test_emulated_state_dict_moves_between_engines(emu):
-    import torch
-    kw = dict(n_nodes=8, n_edges=14, device="cpu", _library=emu, obs_mode="flat")
-    a = ge.VectorGraphEnv("ShortestPath-v0", 7, **kw)
-    a.reset(seed=3); a.random_rollout(5, policy_seed=1)
-    sd = a.state_dict()
-    b = ge.VectorGraphEnv("ShortestPath-v0", 7, **kw)
-    b.load_state_dict(sd)
-    for k in range(12):
-        a.random_rollout(1, policy_seed=1); b.random_rollout(1, policy_seed=1)
-        for key in ("reward", "terminated", "mask", "slot_rec", "node_bits", "episode", "seed", "x"):
-            assert torch.equal(a.t[key], b.t[key]), (k, key)
+    hc.check_state_dict_move(ge, "cpu", emu)
 
 
 def test_emulated_return_graph_obs_and_copy_outputs(emu):
-    env = ge.VectorGraphEnv("ShortestPath-v0", 4, 8, 14, device="cpu", _library=emu, obs_mode="flat", return_graph_obs=True, copy_outputs=True)
-    obs, info = env.reset(seed=1)
-    g = info["graph_obs"]
-    assert g.nodes.shape == (4, 8, env.F) and g.edges.shape == (4, 28, 1) and g.edge_links.shape == (4, 28, 2)
-    flat = np.concatenate([g.nodes.reshape(4, -1).numpy(), g.edges.reshape(4, -1).numpy(), g.edge_links.reshape(4, -1).numpy().astype(np.float32)], axis=1)
-    assert np.array_equal(flat, obs.numpy())  # utils.vectorize_graph of info['graph_obs'] is the observation (tests/test_shortest_path.py:20-24 of the reference)
-    a = env.sample_random_actions(policy_seed=1).clone()
-    _, rew1, _, _, info1 = env.step(a)
-    keep = rew1.clone()
-    env.step(env.sample_random_actions(policy_seed=1).clone())
-    assert (rew1 == keep).all()  # copy_outputs: what step() returned is not overwritten by the next step
-    single = ge.GraphEnv("ShortestPath-v0", n_nodes=8, n_edges=14, device="cpu", _library=emu, return_graph_obs=True)
-    o, inf = single.reset(seed=1)
-    assert np.array_equal(inf["graph_obs"].nodes, g.nodes[1 - 1 + 0].numpy()) or inf["graph_obs"].nodes.shape == (8, env.F)
+    hc.check_graph_obs(ge, "cpu", emu)

@@ -183,8 +183,8 @@ def test_pyg_view_matches_flat_codec():
 
 @pytest.mark.parametrize("env_id,kw,B,K", [
     ("ShortestPath-v0", dict(n_nodes=64, n_edges=192), 65536, 60),     # BASELINE config 2
-    ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), 2048, 130),  # config 3 shape, reduced batch
-    ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 2048, 40),  # config 4 shape, one shard slice
+    ("TSP-v0", dict(n_nodes=128, n_edges=8128, parenting=1), 16384, 130),  # BASELINE config 3, full batch, one whole episode
+    ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 16384, 40),  # BASELINE config 4: one GPU's shard of the 131 072
 ])
 def test_full_size_invariants_and_sampled_oracle_parity(env_id, kw, B, K):
     """At BASELINE sizes: size-independent invariants on every slot + exact oracle replay of sampled slots."""
@@ -520,3 +520,25 @@ def test_randomized_invalid_and_noop_actions(chunk):
         env.close()
         done_cfgs += 1
     assert done_cfgs >= 5
+
+
+def test_call_order_is_guarded():
+    import host_checks as hc
+    hc.check_call_order(_ge(), "cuda", None)
+
+
+@pytest.mark.parametrize("mode", [True, "next_step"])
+def test_inject_with_seeds_then_autoreset(mode):
+    import host_checks as hc
+    import oracle
+    hc.check_inject_seeds_autoreset(_ge(), oracle, "cuda", None, mode)
+
+
+def test_state_dict_moves_between_engines():
+    import host_checks as hc
+    hc.check_state_dict_move(_ge(), "cuda", None)
+
+
+def test_return_graph_obs_and_copy_outputs():
+    import host_checks as hc
+    hc.check_graph_obs(_ge(), "cuda", None)
