@@ -31,8 +31,8 @@ int main(int argc, char **argv) {
   b.heuristic = dev<double>(B); b.mt_state = dev<uint32_t>((size_t)B * GE_SEED_DEPTH * 2 * 624);
   b.mask = dev<uint8_t>((size_t)B * L.A); b.mask_bits = dev<uint64_t>(B * AW); b.reward = dev<double>(B); b.terminated = dev<uint8_t>(B);
   b.invalid = dev<uint8_t>(B); b.solved = dev<int8_t>(B); b.final_cost = dev<double>(B); b.final_heur = dev<double>(B);
-  b.final_len = dev<int32_t>(B); b.reset_list = dev<int32_t>((size_t)GE_SEED_DEPTH * B); b.reset_count = dev<int32_t>((size_t)GE_SEED_DEPTH * ((B + 255) / 256));
-  b.seed_jobs = dev<uint32_t>((size_t)GE_SEED_DEPTH * B * 2); b.work_list = dev<int32_t>(B); b.work_count = dev<int32_t>(4);
+  b.final_len = dev<int32_t>(B); b.reset_list = dev<int32_t>(B); b.reset_count = dev<int32_t>((B + 255) / 256);
+  b.work_list = dev<int32_t>(B); b.work_count = dev<int32_t>(4);
   ge_engine *e = nullptr; GE(ge_create(&cfg, &b, &e));
 
   std::vector<uint32_t> seeds(B); for (int i = 0; i < B; i++) seeds[i] = (uint32_t)i;

@@ -50,7 +50,7 @@ BUFFER_FIELDS = [
     "x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "slot_rec", "terminals",
     "node_bits", "target_bits", "counters", "seed", "episode", "heuristic", "mt_state", "aux_bits",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
-    "final_len", "reset_list", "reset_count", "seed_jobs", "work_list", "work_count", "feat_scratch",
+    "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
     "node_aux", "range_bits", "cover_bits", "actions_out",
 ]
 SEED_DEPTH = 3  # GE_SEED_DEPTH
@@ -63,7 +63,7 @@ class GeBuffers(C.Structure):
 # every symbol include/graphenvs.h declares
 SYMBOLS = [
     "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_reset", "ge_step", "ge_step_only",
-    "ge_reset_pending", "ge_inject_state", "ge_queue_generation", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
+    "ge_reset_pending", "ge_inject_state", "ge_mark_restored", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
     "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash",
 ]
 
@@ -142,8 +142,8 @@ def bind(lib):
     lib.ge_reset_pending.argtypes = [vp, vp]
     lib.ge_inject_state.restype = C.c_int
     lib.ge_inject_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
-    lib.ge_queue_generation.restype = C.c_int
-    lib.ge_queue_generation.argtypes = [vp, C.c_int]
+    lib.ge_mark_restored.restype = C.c_int
+    lib.ge_mark_restored.argtypes = [vp]
     lib.ge_vectorize.restype = C.c_int
     lib.ge_vectorize.argtypes = [vp, vp, vp]
     lib.ge_sample_actions.restype = C.c_int

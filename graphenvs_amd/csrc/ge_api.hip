@@ -20,17 +20,7 @@ struct ge_engine {
   int feat_lds, feat_grid, feat_fast, gen_grid;  // structural-feature kernel launch geometry
   hipEvent_t ev[4];
   bool have_events;
-  // MT19937 pre-seeding on a side stream, GE_SEED_DEPTH episodes ahead.  Generation g = (number of step launches) mod
-  // GE_SEED_DEPTH names one entry of the queue ring (reset_list / reset_count / seed_jobs): step g fills it, the side
-  // stream's seeding kernel reads it, and the main stream only has to wait for that kernel before generation g comes round
-  // again GE_SEED_DEPTH steps later -- by then it has long finished, so the wait never stalls.
-  hipStream_t side;
-  bool have_side;
-  hipEvent_t ev_graph[GE_SEED_DEPTH];   // main stream: the reset kernel of generation g has written its jobs and consumed its states
-  hipEvent_t ev_seeded[GE_SEED_DEPTH];  // side stream: the seeding kernel of generation g is done
-  bool seed_pending[GE_SEED_DEPTH];
-  hipEvent_t ev_ahead; bool ahead_pending;  // side stream: the states of episodes 1.. after a full reset / seeded injection
-  int gen;        // generation of the most recent step launch (its queue is the one ge_reset_pending consumes)
+  int nseed;      // seeding workgroups at the head of the queue-mode reset launch (64 queued slots each)
   bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
   bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
 };
@@ -162,7 +152,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
                         bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->counters, bufs->seed,
                         bufs->episode, bufs->heuristic, bufs->mt_state, bufs->mask, bufs->mask_bits, bufs->reward,
                         bufs->terminated, bufs->invalid, bufs->solved, bufs->final_cost, bufs->final_heur, bufs->final_len,
-                        bufs->reset_list, bufs->reset_count, bufs->seed_jobs, bufs->work_list, bufs->work_count};
+                        bufs->reset_list, bufs->reset_count, bufs->work_list, bufs->work_count};
   for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required device buffer is null");
   if (P.env_type == GE_STEINER_TREE && !bufs->rev_edge) return fail(GE_E_BADARG, "SteinerTree needs rev_edge");
   if (P.env_type == GE_DISTRIBUTION_CENTER && (!bufs->range_bits || !bufs->cover_bits)) return fail(GE_E_BADARG, "DistributionCenter needs range_bits and cover_bits");
@@ -175,33 +165,14 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   P.buf = *bufs;
   ge_engine *e = new (std::nothrow) ge_engine();
   if (!e) return fail(GE_E_BADARG, "out of host memory");
-  e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false; e->have_side = false;
-  e->gen = 0; e->loaded = false; e->seeded = false; e->ahead_pending = false;
-  for (int g = 0; g < GE_SEED_DEPTH; g++) e->seed_pending[g] = false;
-  {
-    bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
-    int made = 0;
-    for (int g = 0; ok && g < GE_SEED_DEPTH; g++) {
-      ok = hipEventCreateWithFlags(&e->ev_graph[g], hipEventDisableTiming) == hipSuccess; if (ok) made++;
-      if (ok) { ok = hipEventCreateWithFlags(&e->ev_seeded[g], hipEventDisableTiming) == hipSuccess; if (ok) made++; }
-    }
-    if (ok) { ok = hipEventCreateWithFlags(&e->ev_ahead, hipEventDisableTiming) == hipSuccess; if (ok) made++; }
-    if (!ok) {  // undo exactly what was made
-      for (int k = 0; k < made; k++) {
-        if (k == 2 * GE_SEED_DEPTH) (void)hipEventDestroy(e->ev_ahead);
-        else (void)hipEventDestroy((k & 1) ? e->ev_seeded[k >> 1] : e->ev_graph[k >> 1]);
-      }
-      if (made > 0 || e->side) (void)hipStreamDestroy(e->side);
-      delete e;
-      return fail(GE_E_LAUNCH, "cannot create the side stream / events");
-    }
-    e->have_side = true;
-  }
+  e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false;
+  e->loaded = false; e->seeded = false;
   int per_cu = kMaxLds / (P.lds.total > 0 ? P.lds.total : 1);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
   e->reset_grid = 256 * per_cu;
   if (e->reset_grid > P.B) e->reset_grid = P.B;
+  e->nseed = (e->reset_grid + 63) / 64;  // one seeding workgroup per 64 regenerating workgroups: the usual queue fits one round of both
   if (P.lds.total > 64 * 1024) {
     hipError_t hr = hipSuccess;
     GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset<ENV>, P.lds.total));
@@ -227,12 +198,6 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
 
 extern "C" int ge_destroy(ge_engine *e) {
   if (!e) return GE_OK;
-  if (e->have_side) {
-    (void)hipStreamSynchronize(e->side);
-    (void)hipStreamDestroy(e->side);
-    for (int g = 0; g < GE_SEED_DEPTH; g++) { (void)hipEventDestroy(e->ev_graph[g]); (void)hipEventDestroy(e->ev_seeded[g]); }
-    (void)hipEventDestroy(e->ev_ahead);
-  }
   if (e->have_events) for (int k = 0; k < 4; k++) (void)hipEventDestroy(e->ev[k]);
   delete e;
   return GE_OK;
@@ -244,44 +209,31 @@ static int check_launch(const char *what) {
   return GE_OK;
 }
 
-static int launch_seed(ge_engine *e, const uint32_t *seeds, int smode, int gen, hipStream_t st) {
-  const int64_t count = (smode == GE_SEED_AHEAD) ? (int64_t)e->P.B * GE_SEED_DEPTH : e->P.B;
-  int grid = (int)((count + 255) / 256);
-  size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
-  GE_LAUNCH(ge_k_seed, grid, 256, lds, st, e->P, seeds, smode, gen);
+// ring entries jlo .. GE_SEED_DEPTH - 1 of every slot from seeds[] (+ j * seed_stride), on the caller's stream
+static int launch_seed(ge_engine *e, const uint32_t *seeds, int jlo, void *stream) {
+  const int64_t items = (int64_t)(GE_SEED_DEPTH - jlo) * e->P.B;
+  int64_t grid = (items + GE_WAVE - 1) / GE_WAVE;
+  if (grid > 8192) grid = 8192;
+  GE_LAUNCH(ge_k_seed, (int)grid, 2 * GE_WAVE, GE_SEED_LDS_BYTES, stream, e->P, seeds, jlo);
   return check_launch("seed kernel");
 }
 
-// the main stream is about to reuse generation `gen` of the queue ring: the side stream's seeding kernel that read it
-// GE_SEED_DEPTH steps ago must be done (it is, unless the device is badly oversubscribed: this wait does not stall)
-static void wait_generation(ge_engine *e, int gen, void *stream) {
-  if (e->seed_pending[gen]) { (void)hipStreamWaitEvent((hipStream_t)stream, e->ev_seeded[gen], 0); e->seed_pending[gen] = false; }
-}
-// the states of episodes 1.. written after a full reset must be there before the first queued regeneration reads them
-static void wait_ahead(ge_engine *e, void *stream) {
-  if (e->ahead_pending) { (void)hipStreamWaitEvent((hipStream_t)stream, e->ev_ahead, 0); e->ahead_pending = false; }
-}
-static void wait_all_side(ge_engine *e, void *stream) {
-  for (int g = 0; g < GE_SEED_DEPTH; g++) wait_generation(e, g, stream);
-  wait_ahead(e, stream);
-}
-
-static int launch_features(ge_engine *e, int mode, int gen, void *stream) {
+static int launch_features(ge_engine *e, int mode, void *stream) {
   int rc = GE_OK;
   int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);
   if (e->feat_fast) {
-    GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode, gen);
+    GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode);
     rc = check_launch("feature kernel (n <= 64)");
     if (rc != GE_OK) return rc;
     int g2 = e->gen_grid < 64 ? e->gen_grid : 64;  // normally an empty list
-    GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST, gen);
+    GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
     return check_launch("feature kernel (fallback list)");
   }
   {
     int64_t want = (int64_t)fgrid * e->P.feat_parts;
     if (mode == GE_RESET_QUEUE && want > 4096) want = 4096;  // queue mode: the list is short, workgroups stride over it
     if (want > 65535 * 16) want = 65535 * 16;
-    GE_LAUNCH(ge_k_features, (int)want, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode, gen);
+    GE_LAUNCH(ge_k_features, (int)want, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode);
   }
   rc = check_launch("feature kernel");
   if (rc != GE_OK || e->P.feat_parts == 1) return rc;
@@ -289,53 +241,30 @@ static int launch_features(ge_engine *e, int mode, int gen, void *stream) {
     size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
     int64_t items = (int64_t)(mode == GE_RESET_QUEUE ? 4096 : e->P.B) * e->P.n;
     int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
-    GE_LAUNCH(ge_k_feat_combine, grid, 256, lds, stream, e->P, mode, gen);
+    GE_LAUNCH(ge_k_feat_combine, grid, 256, lds, stream, e->P, mode);
   }
   return check_launch("feature combine kernel");
 }
 
-// mode GE_RESET_ALL / GE_RESET_INJECT: every slot; GE_RESET_QUEUE: the slots step generation `gen` queued
-static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, int gen, void *stream) {
+// mode GE_RESET_ALL / GE_RESET_INJECT: every slot; GE_RESET_QUEUE: the slots the last step launch queued.  Everything on the
+// caller's stream, in order: generator states (full reset: the ring of every slot; queue mode: seeding workgroups inside the
+// reset launch), graph kernel, feature kernel(s).
+static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, void *stream) {
   int rc = GE_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const bool restart = (mode == GE_RESET_ALL) || (mode == GE_RESET_INJECT && inj.seeds);
-  if (mode != GE_RESET_QUEUE) wait_all_side(e, stream);  // nothing of the side stream may still read or write what a full reset / injection rewrites
-  else wait_ahead(e, stream);
-  if (mode == GE_RESET_ALL) {  // states of episode 0 on the main stream, right in front of their consumer
-    rc = launch_seed(e, seeds, GE_SEED_GIVEN, 0, st);
-    if (rc != GE_OK) return rc;
-  }
-  int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_reset<ENV>, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj, gen));
+  if (mode == GE_RESET_ALL) rc = launch_seed(e, seeds, 0, stream);
+  else if (mode == GE_RESET_INJECT && inj.seeds) rc = launch_seed(e, inj.seeds, 1, stream);  // the injected episode needs no states of its own
+  if (rc != GE_OK) return rc;
+  int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid + e->nseed : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
+  GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_reset<ENV>, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj, e->nseed));
   rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;
-  if (mode != GE_RESET_INJECT) {
-    rc = launch_features(e, mode, gen, stream);
-    if (rc != GE_OK) return rc;
-  }
-  // side stream: generator states of the episodes ahead.  The event is recorded behind the feature kernel -- the reset kernel's
-  // consumer runs back to back with it, and the seeding kernel has GE_SEED_DEPTH - 1 whole steps before anyone waits for it.
-  if (mode == GE_RESET_QUEUE) {
-    (void)hipEventRecord(e->ev_graph[gen], st);
-    (void)hipStreamWaitEvent(e->side, e->ev_graph[gen], 0);
-    rc = launch_seed(e, nullptr, GE_SEED_JOBS, gen, e->side);
-    if (rc != GE_OK) return rc;
-    (void)hipEventRecord(e->ev_seeded[gen], e->side);
-    e->seed_pending[gen] = true;
-  } else if (restart) {
-    (void)hipEventRecord(e->ev_graph[0], st);
-    (void)hipStreamWaitEvent(e->side, e->ev_graph[0], 0);
-    rc = launch_seed(e, nullptr, GE_SEED_AHEAD, 0, e->side);
-    if (rc != GE_OK) return rc;
-    (void)hipEventRecord(e->ev_ahead, e->side);
-    e->ahead_pending = true;
-    e->seeded = true;
-  }
-  return GE_OK;
+  if (mode != GE_RESET_INJECT) rc = launch_features(e, mode, stream);
+  if (rc == GE_OK && (mode == GE_RESET_ALL || inj.seeds)) e->seeded = true;
+  return rc;
 }
 
-static int clear_queues(ge_engine *e, void *stream) {  // a full reset / injection leaves every generation of the queue ring empty
-  const size_t bytes = sizeof(int32_t) * (size_t)GE_SEED_DEPTH * (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK);
+static int clear_queue(ge_engine *e, void *stream) {  // a full reset / injection leaves the finished-slot queue empty
+  const size_t bytes = sizeof(int32_t) * (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK);
   if (hipMemsetAsync(e->P.buf.reset_count, 0, bytes, (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
   return GE_OK;
 }
@@ -343,10 +272,9 @@ static int clear_queues(ge_engine *e, void *stream) {  // a full reset / injecti
 extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
   if (!e || !seeds) return fail(GE_E_BADARG, "null argument");
   GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  wait_all_side(e, stream);
-  int rc = clear_queues(e, stream);
+  int rc = clear_queue(e, stream);
   if (rc != GE_OK) return rc;
-  rc = launch_reset(e, seeds, GE_RESET_ALL, none, 0, stream);
+  rc = launch_reset(e, seeds, GE_RESET_ALL, none, stream);
   if (rc == GE_OK) e->loaded = true;
   return rc;
 }
@@ -361,10 +289,9 @@ extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t
   if (!seeds && e->P.autoreset && !e->seeded)
     return fail(GE_E_STATE, "ge_inject_state without seeds on an engine with autoreset whose generator states were never seeded: pass seeds, or call ge_reset first");
   GeInject inj = {links, wcode, x, terminals, seeds};
-  wait_all_side(e, stream);
-  int rc = clear_queues(e, stream);  // slots queued before the injection must not be regenerated over the injected state
+  int rc = clear_queue(e, stream);  // slots queued before the injection must not be regenerated over the injected state
   if (rc != GE_OK) return rc;
-  rc = launch_reset(e, nullptr, GE_RESET_INJECT, inj, 0, stream);
+  rc = launch_reset(e, nullptr, GE_RESET_INJECT, inj, stream);
   if (rc == GE_OK) e->loaded = true;
   return rc;
 }
@@ -385,13 +312,6 @@ static int check_state(const ge_engine *e) {
   return GE_OK;
 }
 
-// every step launch opens the next generation of the queue ring
-static int next_generation(ge_engine *e, void *stream) {
-  e->gen = (e->gen + 1) % GE_SEED_DEPTH;
-  wait_generation(e, e->gen, stream);
-  return e->gen;
-}
-
 extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) {
   if (!e || !actions) return fail(GE_E_BADARG, "null argument");
   int rc = check_state(e);
@@ -401,10 +321,9 @@ extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) 
     rc = check_launch("coverage range kernel");
     if (rc != GE_OK) return rc;
   }
-  const int gen = next_generation(e, stream);
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0, gen);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0, gen));
+  if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0));
   return check_launch("step kernel");
 }
 
@@ -418,10 +337,9 @@ static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch,
     rc = ge_sample_actions(e, policy_seed, scratch, stream);
     return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
   }
-  const int gen = next_generation(e, stream);
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (path64(e)) GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed, gen);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed, gen));
+  if (path64(e)) GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed));
   return check_launch("fused sample+step kernel");
 }
 
@@ -432,7 +350,7 @@ extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
   if (rc != GE_OK) return rc;
   if (e->P.autoreset) {
     GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, none, e->gen, stream);
+    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, none, stream);
   }
   return rc;
 }
@@ -448,11 +366,12 @@ extern "C" int ge_step(ge_engine *e, const int64_t *actions, void *stream) {
   return ge_reset_pending(e, stream);
 }
 
-// generation of the queue ring the next ge_reset_pending consumes (state_dict round trips between engines): set >= 0 to load it
-extern "C" int ge_queue_generation(ge_engine *e, int set) {
+// Checkpointing: the slabs are the whole state.  An engine whose slabs were restored from a snapshot of a reset engine holds an
+// episode and a seeded generator ring.
+extern "C" int ge_mark_restored(ge_engine *e) {
   if (!e) return GE_E_BADARG;
-  if (set >= 0) { e->gen = set % GE_SEED_DEPTH; e->loaded = true; e->seeded = true; }
-  return e->gen;
+  e->loaded = true; e->seeded = true;
+  return GE_OK;
 }
 
 extern "C" int ge_vectorize(ge_engine *e, float *out, void *stream) {

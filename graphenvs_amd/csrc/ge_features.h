@@ -399,28 +399,29 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
 enum { GE_FEAT_LIST = 3 };  // slots from work_list (fallback of the fast path)
 
 // mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list
-GE_KERNEL ge_k_features(GeParams P, int mode, int gen) {
+GE_KERNEL ge_k_features(GeParams P, int mode) {
   int *pre = (int *)(ge_dyn_smem() + P.ldsf.pre);
   int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
   if (mode == GE_RESET_QUEUE) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
   const int nparts = (mode == GE_FEAT_LIST) ? 1 : P.feat_parts;
   for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
     const int item = q / nparts;
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item, gen) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
+    if (mode == GE_RESET_QUEUE && q % nparts == 0 && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
     ge_features_generic_env(P, env, q % nparts, nparts);
   }
 }
 
 // betweenness of multi-part slots: parts added in part order, then the 1/((n-1)(n-2)) rescale and the float32 cast
-GE_KERNEL ge_k_feat_combine(GeParams P, int mode, int gen) {
+GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
   int *pre = (int *)ge_dyn_smem();
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
@@ -428,7 +429,7 @@ GE_KERNEL ge_k_feat_combine(GeParams P, int mode, int gen) {
   const double scale = n > 2 ? 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)) : 1.0;
   for (int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid(); g < (int64_t)count * n; g += (int64_t)ge_gdim() * ge_bdim()) {
     const int item = (int)(g / n), v = (int)(g % n);
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item, gen) : item;
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : item;
     double acc = 0.0;
     for (int p = 0; p < nparts; p++) acc += P.buf.feat_scratch[((int64_t)env * nparts + p) * n + v];
     if (n > 2) acc *= scale;
@@ -436,17 +437,18 @@ GE_KERNEL ge_k_feat_combine(GeParams P, int mode, int gen) {
   }
 }
 
-GE_KERNEL ge_k_features64(GeParams P, int mode, int gen) {
+GE_KERNEL ge_k_features64(GeParams P, int mode) {
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   int *pre = ge_f64_pre(P.E, P.env_type == GE_TSP, nblk);
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {  // the prefix scan is one wave wide
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[nblk];
   }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q, gen) : q;
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    if (mode == GE_RESET_QUEUE && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
     ge_features64_env(P, env, pre + nblk + 1);
   }
 }

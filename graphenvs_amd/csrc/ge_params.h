@@ -14,6 +14,8 @@
 #define GE_STEP_BLOCK 256
 #endif
 #define GE_RESET_THREADS 128
+#define GE_SEED_TILE_STRIDE 68  // u32 per row of a seeding tile [16 words][64 slots]: 68 mod 64 = 4, the flush reads 64 different banks
+#define GE_SEED_LDS_BYTES (2 * 16 * GE_SEED_TILE_STRIDE * 4 + 64 * 4 + 64)
 #ifndef GE_RESET_WAVES_PER_SIMD
 #define GE_RESET_WAVES_PER_SIMD 6  // 24 waves / CU = 12 two-wave workgroups: one round for the ~2 700 resets of a headline step
 #endif
@@ -94,6 +96,7 @@ static inline void ge_make_lds(GeParams &P) {
   L.kou = (P.env_type == GE_STEINER_TREE && P.is_eval && P.n_dests > 1 && P.n_dests < P.n - 1) ? take(2 * P.n * P.W * 8 + P.T * 16) : 0;
   // the queue prefix is only needed while a workgroup looks up its slot: it overlays the scratch that follows
   { int pb = ((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4; L.pre = L.mt; if (pb > GE_MT_N * 8) { L.pre = take(pb); } }
+  if (o < GE_SEED_LDS_BYTES) o = GE_SEED_LDS_BYTES;  // the seeding workgroups of the queue-mode launch use the same allocation
   L.total = o;
 }
 

@@ -14,6 +14,7 @@
 #define GE_KERNEL __global__ void
 #define GE_KERNEL_LB(threads, waves_per_simd) __global__ void __launch_bounds__(threads, waves_per_simd)
 #define GE_HOSTDEV __host__ __device__ inline
+#define GE_CONSTANT static __constant__ const
 
 GE_DEV int ge_tid() { return (int)threadIdx.x; }
 // The same value behind an opaque move.  Read at the top of the per-slot body of a persistent (slot-loop) kernel, it keeps the

@@ -890,7 +890,7 @@ GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, cons
 }
 
 template <int ENV>
-GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, int mode, const GeInject &inj, int gen, int qidx) {
+GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, int mode, const GeInject &inj) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
   // Inside a wave only wave-level hand-offs are used; the two block barriers are the join and the end of the slot.
   const int tid = ge_tid_fresh();
@@ -901,9 +901,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   const bool path_like_t = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   GeRctx c = ge_carve(P);
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
-  // episode bookkeeping (written by this kernel only).  A full reset or an injection with seeds starts episode 0 with the given
-  // seed; a queued slot moves to its next episode, whose generator states sit in ring entry (episode mod GE_SEED_DEPTH); an
-  // injection without seeds leaves seed / episode alone (the episodes that follow continue the earlier sequence)
+  // episode bookkeeping.  A full reset or an injection with seeds starts episode 0 with the given seed; a queued slot moves to
+  // its next episode, whose generator states sit in ring entry (episode mod GE_SEED_DEPTH); an injection without seeds leaves
+  // seed / episode alone (the episodes that follow continue the earlier sequence).  In queue mode seed[] / episode[] still hold
+  // the OLD episode while this kernel runs -- its seeding workgroups read them too -- and the feature kernel, the last kernel
+  // of a regeneration, advances them (ge_advance_episode).
   const bool restart = (mode == GE_RESET_ALL) || (mode == GE_RESET_INJECT && inj.seeds);
   const int64_t episode = restart ? 0 : P.buf.episode[env] + (mode == GE_RESET_QUEUE ? 1 : 0);
   const uint32_t seed = restart ? (mode == GE_RESET_ALL ? seeds[env] : inj.seeds[env]) : P.buf.seed[env] + (mode == GE_RESET_QUEUE ? (uint32_t)P.seed_stride : 0u);
@@ -1432,13 +1434,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
     if (mode == GE_RESET_QUEUE) G.final_heur[env] = G.heuristic[env];  // of the episode that just ended (same-step autoreset reads it after this kernel)
     G.heuristic[env] = heuristic;
+    if (mode != GE_RESET_QUEUE) { G.seed[env] = seed; G.episode[env] = episode; }
     if (t == GE_PERISHABLE_DELIVERY && mode != GE_RESET_INJECT) G.target_bits[(int64_t)env * W] = ge_f64_as_u64(ppd_dt);  // info['time_left'] of reset() (perishable_product_delivery.py:158) as float64 bits: this env has no target set
-    G.seed[env] = seed; G.episode[env] = episode;
-    if (mode == GE_RESET_QUEUE) {  // the ring entry just consumed gets the states of the episode GE_SEED_DEPTH ahead (side stream)
-      uint32_t *job = G.seed_jobs + ((int64_t)gen * P.B + qidx) * 2;
-      job[0] = (uint32_t)env | ((uint32_t)ring << 28);
-      job[1] = seed + (uint32_t)GE_SEED_DEPTH * (uint32_t)P.seed_stride;
-    }
   }
   ge_sync();
   GE_STAMP(10);
@@ -1446,9 +1443,9 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
 
 // Queue mode: every step workgroup left (count, segment) in reset_count / reset_list; each reset workgroup
 // rebuilds the exclusive prefix of the counts in LDS and finds its slot by binary search.
-GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane, int gen) {  // one wave; no barrier
+GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) {  // one wave; no barrier
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  const int32_t *rc = P.buf.reset_count + (int64_t)gen * nblk;
+  const int32_t *rc = P.buf.reset_count;
   int carry = 0;
   for (int k0 = 0; k0 < nblk; k0 += GE_WAVE) {
     int k = k0 + lane; int cnt = k < nblk ? rc[k] : 0;
@@ -1459,86 +1456,175 @@ GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane, int gen) 
   if (lane == 0) pre[nblk] = carry;
   return carry;
 }
-GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q, int gen) {
+GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
   int lo = 0, hi = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid; }
-  return P.buf.reset_list[(int64_t)gen * P.B + lo * GE_STEP_BLOCK + (q - pre[lo])];
+  return P.buf.reset_list[lo * GE_STEP_BLOCK + (q - pre[lo])];
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// MT19937 pre-seeding, one LANE per slot.  Seeding is a chain of 1 246 + 623 dependent steps; inside the reset
-// workgroup it kept one lane busy and 63 idle.  Here 64 slots seed side by side and the kernel runs on the engine's
-// side stream while the feature kernel of the same vector step occupies the main stream, so neither its latency nor
-// its instructions are on the step's critical path.  State layout [slot][stream][624]: the reset workgroup loads
-// its 2 x 2.5 KB with coalesced reads.
-// GE_SEED_GIVEN: ring entry 0 of every slot from seeds[] (episode 0; main stream, in front of the full reset);
-// GE_SEED_AHEAD: entries of episodes 1 .. GE_SEED_DEPTH of every slot from seed[] (side stream, after a full reset or a seeded injection);
-// GE_SEED_JOBS: the jobs the queue-mode reset kernel of generation `gen` left in seed_jobs (side stream).
-enum { GE_SEED_GIVEN = 0, GE_SEED_AHEAD = 1, GE_SEED_JOBS = 2 };
+// MT19937 pre-seeding, GE_SEED_DEPTH - 1 episodes ahead.  Seeding is a chain of 1 246 + 623 dependent steps per slot; one LANE
+// runs the chain of one slot entirely in registers (the pass-1 words that init_by_array's second pass consumes are recomputed
+// in step with it instead of being stored and read back), so a wave seeds 64 slots side by side.  Every 16 words the wave
+// transposes its [16 words][64 slots] tile through LDS and writes it as 64-byte pieces, four slots per store instruction:
+// the states leave as full sectors instead of 1 869 scattered 4-byte stores per slot (which kept a whole launch busy for
+// ~190 us and slowed whatever ran beside it).  A seeding workgroup is two waves: wave 0 the python stream (random.seed(int) =
+// init_by_array([s])), wave 1 the numpy stream (np.random.seed(int) = init_genrand(s)) of the same 64 slots.
+// The ring: the generator states of episode e sit in entry e mod GE_SEED_DEPTH.  While a slot runs episode e, entries (e+1) and
+// (e+2) are valid and entry e is free; the launch that moves it to e+1 reads entry (e+1) and refills entry e with episode e+3.
 
-GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int mode, int gen) {
-  int *pre = (int *)ge_dyn_smem();
-  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  int64_t count = (mode == GE_SEED_AHEAD) ? (int64_t)P.B * GE_SEED_DEPTH : P.B;
-  if (mode == GE_SEED_JOBS) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
-    ge_sync();
-    count = pre[nblk];
+// init_genrand(19650218): the constant sequence init_by_array starts from, evaluated at compile time (the chain that produces
+// it is as long as the one it feeds: as a table it costs one scalar load per step instead of three vector operations)
+struct GeMtInit { uint32_t v[GE_MT_N]; };
+constexpr GeMtInit ge_make_mt_init() {
+  GeMtInit t{};
+  uint32_t b = 19650218u;
+  t.v[0] = b;
+  for (int i = 1; i < GE_MT_N; i++) { b = 1812433253u * (b ^ (b >> 30)) + (uint32_t)i; t.v[i] = b; }
+  return t;
+}
+GE_CONSTANT GeMtInit ge_mt_init = ge_make_mt_init();
+
+// per-lane destinations of a tile flush: lane (sub, w) = (lane >> 4, lane & 15) writes word w of the slots 4 r + sub, r = 0..15.
+// cb[r] = index of the slot's first 16-word piece in mt_state (one register per slot instead of a 64-bit pointer), 0xffffffff = none.
+struct GeSeedDst { uint32_t cb[16]; };
+GE_DEV GeSeedDst ge_seed_dst(const uint32_t *base, int stream, int lane) {
+  GeSeedDst d;
+  const int sub = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const uint32_t sb = base[4 * r + sub];
+    d.cb[r] = (sb != 0xffffffffu) ? (sb * 2u + (uint32_t)stream) * (uint32_t)(GE_MT_N / 16) : 0xffffffffu;
   }
-  const int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid();
-  if (g >= count) return;
-  int env, ring; uint32_t seed;
-  if (mode == GE_SEED_GIVEN) { env = (int)g; ring = 0; seed = seeds[env]; }
-  else if (mode == GE_SEED_AHEAD) {  // lanes of a wave share the episode offset, consecutive lanes take consecutive slots
-    const int j = (int)(g / P.B) + 1; env = (int)(g % P.B);
-    ring = (int)((P.buf.episode[env] + j) % GE_SEED_DEPTH); seed = P.buf.seed[env] + (uint32_t)j * (uint32_t)P.seed_stride;
-  } else {
-    const uint32_t *job = P.buf.seed_jobs + ((int64_t)gen * P.B + g) * 2;
-    env = (int)(job[0] & 0x0fffffffu); ring = (int)(job[0] >> 28); seed = job[1];
+  return d;
+}
+// write the tile (words [16 c, 16 c + 16) of 64 slots) to the slots' state arrays as 64-byte pieces.  Collective over the wave.
+GE_DEV void ge_seed_flush(const GeParams &P, const uint32_t *tile, const GeSeedDst &d, int c, int lane) {
+  ge_wave_sync();
+  const uint32_t *src = tile + (lane & 15) * GE_SEED_TILE_STRIDE + (lane >> 4);
+  uint32_t *out = P.buf.mt_state + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const uint32_t v = src[4 * r];
+    if (d.cb[r] != 0xffffffffu) out[(int64_t)(d.cb[r] + (uint32_t)c) * 16] = v;
   }
-  uint32_t *mt = P.buf.mt_state + ((int64_t)env * GE_SEED_DEPTH + ring) * 2 * GE_MT_N;
-  {  // python: init_by_array([seed])
-    uint32_t b = 19650218u, prev = b;
-    for (int i = 1; i < GE_MT_N; i++) {
-      b = 1812433253u * (b ^ (b >> 30)) + (uint32_t)i;
-      prev = (b ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;
-      mt[i] = prev;
+  ge_wave_sync();
+}
+
+// one seeding workgroup (two waves) over 64 (slot, ring entry, seed) items: `sb` = slot * GE_SEED_DEPTH + entry of this lane's
+// item or 0xffffffff.  `lds` = GE_SEED_LDS_BYTES of scratch.  Collective over the workgroup (wave-level syncs only).
+GE_DEV void ge_seed_group(const GeParams &P, unsigned char *lds, uint32_t sb, uint32_t seed, int tid) {
+  const int lane = tid & (GE_WAVE - 1), wv = tid >> 6;
+  uint32_t *tile = (uint32_t *)lds + wv * 16 * GE_SEED_TILE_STRIDE;
+  uint32_t *base = (uint32_t *)lds + 2 * 16 * GE_SEED_TILE_STRIDE;  // shared by both waves: same items
+  if (wv == 0) base[lane] = sb;
+  ge_sync();
+  const GeSeedDst dst = ge_seed_dst(base, wv, lane);
+  uint32_t *mine = tile + lane;
+  if (wv == 0) {  // python: init_by_array([seed]) ([py] _randommodule.c)
+    uint32_t prev = 19650218u, first = 0u;
+    for (int i = 1; i < GE_MT_N; i++) {  // pass 1, to its end: only its last word and mt[1] are needed to start pass 2
+      prev = (ge_mt_init.v[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;  // + key[0] + j, j == 0
+      if (i == 1) first = prev;
     }
-    prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;
-    uint32_t m1 = prev;
-    for (int i = 2; i < GE_MT_N; i++) {
-      prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-      mt[i] = prev;
+    const uint32_t m1 = (first ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;  // i wrapped: the 624th iteration lands on mt[1]
+    prev = m1;
+    uint32_t p1 = first;  // pass 1 again, in step with pass 2 (its words are consumed once, in order: nothing is stored)
+    for (int c = 0; c < GE_MT_N / 16; c++) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int i = 16 * c + k;
+        uint32_t out;
+        if (i == 0) out = 0x80000000u;   // mt[0]
+        else if (i == 1) out = 0u;       // mt[1] is the last word to be known: patched below
+        else {
+          p1 = (ge_mt_init.v[i] ^ ((p1 ^ (p1 >> 30)) * 1664525u)) + seed;          // pass-1 value of mt[i]
+          prev = (p1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;       // final mt[i]
+          out = prev;
+        }
+        mine[k * GE_SEED_TILE_STRIDE] = out;
+      }
+      ge_seed_flush(P, tile, dst, c, lane);
     }
-    mt[1] = (m1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
-    mt[0] = 0x80000000u;
+    if (sb != 0xffffffffu) P.buf.mt_state[((int64_t)sb * 2 + 0) * GE_MT_N + 1] = (m1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+  } else {        // numpy: init_genrand(seed) ([np] mt19937.c)
+    uint32_t prev = seed;
+    for (int c = 0; c < GE_MT_N / 16; c++) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int i = 16 * c + k;
+        if (i > 0) prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
+        mine[k * GE_SEED_TILE_STRIDE] = prev;
+      }
+      ge_seed_flush(P, tile, dst, c, lane);
+    }
   }
-  {  // numpy: init_genrand(seed)
-    uint32_t *mn = mt + GE_MT_N, prev = seed;
-    mn[0] = prev;
-    for (int i = 1; i < GE_MT_N; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; mn[i] = prev; }
+  ge_sync();  // the scratch may be reused
+}
+
+// Full reset / seeded injection: ring entries jlo .. GE_SEED_DEPTH - 1 of every slot, entry j from seeds[slot] + j * seed_stride
+// (episode j of a slot whose first episode is seeded seeds[slot]).  128-thread workgroups, 64 items each.
+GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int jlo) {
+  const int tid = ge_tid();
+  const int64_t items = (int64_t)(GE_SEED_DEPTH - jlo) * P.B;
+  for (int64_t g0 = (int64_t)ge_bid() * GE_WAVE; g0 < items; g0 += (int64_t)ge_gdim() * GE_WAVE) {
+    const int64_t g = g0 + (ge_tid_fresh() & (GE_WAVE - 1));
+    uint32_t sb = 0xffffffffu, seed = 0u;
+    if (g < items) {
+      const int j = jlo + (int)(g / P.B), env = (int)(g % P.B);
+      sb = (uint32_t)env * GE_SEED_DEPTH + (uint32_t)j;
+      seed = seeds[env] + (uint32_t)j * (uint32_t)P.seed_stride;
+    }
+    ge_seed_group(P, ge_dyn_smem(), sb, seed, tid);
   }
 }
 
+// the feature kernel (the last kernel of a queued regeneration) moves the slot's bookkeeping to the new episode
+GE_DEV void ge_advance_episode(const GeParams &P, int env) {
+  P.buf.seed[env] = P.buf.seed[env] + (uint32_t)P.seed_stride;
+  P.buf.episode[env] = P.buf.episode[env] + 1;
+}
+
+// Queue mode: the first `nseed` workgroups of the launch are seeding workgroups (64 queued slots each): they refill the ring
+// entry the slot's PREVIOUS regeneration consumed with the states of the episode GE_SEED_DEPTH ahead of the one that just
+// ended, while the other workgroups regenerate the queued slots from the entries seeded long ago -- no second stream, no event.
 template <int ENV>
-GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj, int gen) {
+GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj, int nseed) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid(), gen);
+    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[nblk];
   }
-  for (int q = ge_bid(); q < count; q += ge_gdim()) {
+  if (mode == GE_RESET_QUEUE && ge_bid() < nseed) {
+    for (int g0 = ge_bid() * GE_WAVE; g0 < count; g0 += nseed * GE_WAVE) {
+      const int tid = ge_tid_fresh();
+      if (g0 != ge_bid() * GE_WAVE) { if (tid < GE_WAVE) ge_queue_prefix_wave(P, pre, tid); ge_sync(); }
+      const int q = g0 + (tid & (GE_WAVE - 1));
+      uint32_t sb = 0xffffffffu, seed = 0u;
+      if (q < count) {
+        const int env = ge_queue_slot(P, pre, q);
+        const int64_t ep = P.buf.episode[env];  // the episode that just ended: its entry is free, episode ep + DEPTH goes there
+        sb = (uint32_t)env * GE_SEED_DEPTH + (uint32_t)(ep % GE_SEED_DEPTH);
+        seed = P.buf.seed[env] + (uint32_t)GE_SEED_DEPTH * (uint32_t)P.seed_stride;
+      }
+      ge_sync();  // every lane has its item before the scratch (which holds the queue prefix) is reused
+      ge_seed_group(P, ge_dyn_smem(), sb, seed, tid);
+    }
+    return;
+  }
+  const int first = (mode == GE_RESET_QUEUE) ? nseed : 0, stride = ge_gdim() - first;
+  for (int q = ge_bid() - first; q < count; q += stride) {
     int env = q;
     if (mode == GE_RESET_QUEUE) {
-      if (q != ge_bid()) { const int t2 = ge_tid_fresh(); if (t2 < GE_WAVE) ge_queue_prefix_wave(P, pre, t2, gen); ge_sync(); }
-      env = ge_queue_slot(P, pre, q, gen);
+      if (q != ge_bid() - first) { const int t2 = ge_tid_fresh(); if (t2 < GE_WAVE) ge_queue_prefix_wave(P, pre, t2); ge_sync(); }
+      env = ge_queue_slot(P, pre, q);
       ge_sync();  // every thread has its slot before the scratch is reused
     }
-    ge_reset_env<ENV>(P, env, seeds, mode, inj, gen, q);
+    ge_reset_env<ENV>(P, env, seeds, mode, inj);
   }
 }

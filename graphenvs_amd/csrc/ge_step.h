@@ -30,9 +30,9 @@ GE_DEV uint64_t ge_rec_make(int head, int status, int aux, uint64_t tstep) {
   return ((uint64_t)head & GE_REC_HEAD_MASK) | ((uint64_t)status << GE_REC_STATUS_SHIFT) | ((uint64_t)aux << GE_REC_AUX_SHIFT) | (tstep << GE_REC_TSTEP_SHIFT);
 }
 
-// Finished slots of this workgroup go to the workgroup's own segment of reset_list (generation `gen` of the queue ring), in slot
-// order, and the segment length to reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
-GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want, int gen) {
+// Finished slots of this workgroup go to the workgroup's own segment of reset_list, in slot order, and the segment length to
+// reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
+GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want) {
   const uint64_t b = ge_ballot(want);
   const int lane = tid & 63, wave = tid >> 6, nw = ge_bdim() >> 6;
   const int rank = ge_popc64(b & ((1ull << lane) - 1ull));
@@ -40,8 +40,8 @@ GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int ti
   ge_sync();
   int off = 0;
   for (int w = 0; w < wave; w++) off += wcnt[w];
-  if (want) P.buf.reset_list[(int64_t)gen * P.B + i0 + off + rank] = i;
-  if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[(int64_t)gen * ge_gdim() + ge_bid()] = tot; }
+  if (want) P.buf.reset_list[i0 + off + rank] = i;
+  if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[ge_bid()] = tot; }
 }
 
 #define GE_MAXW 8  // parenting >= 2 walks the residual graph per thread: node sets of up to 8 words (n <= 512)
@@ -102,7 +102,7 @@ GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
 
 // SAMPLE: the device policy is evaluated here (one launch per rollout step) and the action is also written to actions_out
 template <int ENV, bool SAMPLE>
-GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed, int gen) {
+GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -477,7 +477,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed, in
 
   uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * W);
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, gen);  // contains the barrier
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
   if (edge_mask) return;  // SteinerTree updates its [B, 2m] mask incrementally above
   // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
@@ -517,7 +517,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed, in
 #endif
 #define GE_ON(bit) (!(GE_ABL & (bit)))  // 1 x flag, 2 bool-mask bytes, 4 gather, 8 policy, 16 state stores, 64 output stores
 template <bool SAMPLE>
-GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t policy_seed, int gen) {
+GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t policy_seed) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -618,7 +618,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     }
   }
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, gen);  // contains the barrier
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
   if (nb <= 0 || !GE_ON(2)) return;
   uint8_t *out = G.mask + (int64_t)i0 * n;

@@ -199,9 +199,8 @@ class VectorGraphEnv:
         t["final_cost"] = z((B,), torch.float64)
         t["final_heur"] = z((B,), torch.float64)
         t["final_len"] = z((B,), torch.int32)
-        t["reset_list"] = z((_lib.SEED_DEPTH, B), torch.int32)
-        t["reset_count"] = z((_lib.SEED_DEPTH, (B + 255) // 256), torch.int32)
-        t["seed_jobs"] = z((_lib.SEED_DEPTH, B, 2), torch.int32)
+        t["reset_list"] = z((B,), torch.int32)
+        t["reset_count"] = z(((B + 255) // 256,), torch.int32)
         t["work_list"] = z((B,), torch.int32)
         t["work_count"] = z((4,), torch.int32)
         t["feat_scratch"] = z((B, lay.feat_parts, n), torch.float64) if lay.feat_parts > 1 else None
@@ -420,24 +419,19 @@ class VectorGraphEnv:
         return self._obs(), self._info(False)
 
     def _quiesce(self):
-        # the MT19937 pre-seeding kernel runs on the engine's side stream: drain the device before touching the slabs
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
     def state_dict(self):
-        """Snapshot of every engine slab (the whole state of the batch, generator states included) plus the one host-side
-        number of the engine: the generation of its reset-queue ring."""
+        """Snapshot of every engine slab: the whole state of the batch, generator states included."""
         self._quiesce()
-        sd = {k: v.clone() for k, v in dict.items(self.t) if v is not None}
-        sd["_queue_generation"] = int(self._L.ge_queue_generation(self._h, -1))
-        return sd
+        return {k: v.clone() for k, v in dict.items(self.t) if v is not None}
 
     def load_state_dict(self, sd):
         self._quiesce()
         for k, v in sd.items():
-            if k != "_queue_generation":
-                dict.__getitem__(self.t, k).copy_(v)
-        self._L.ge_queue_generation(self._h, int(sd["_queue_generation"]))
+            dict.__getitem__(self.t, k).copy_(v)
+        self._L.ge_mark_restored(self._h)
         self._was_reset = True
         self._quiesce()
 

@@ -8,11 +8,9 @@
  * Conventions
  *  - plain C types only; every buffer pointer is a DEVICE pointer owned by the caller
  *    (the Python host allocates them with torch); the library never allocates device memory;
- *  - every launch goes to the hipStream_t passed as `stream` (void*, NULL = default stream), except the
- *    MT19937 pre-seeding kernel, which runs on a side stream the engine owns and is ordered against
- *    `stream` with events; no call synchronises the stream or the device.  The side stream only ever reads
- *    and writes engine slabs (seed_jobs, reset_count, mt_state): a pointer the caller passes to a call
- *    (seeds, actions, ...) is consumed on `stream` only and may be reused once `stream` has passed the call;
+ *  - every launch goes to the hipStream_t passed as `stream` (void*, NULL = default stream); the engine owns no stream
+ *    of its own and no call synchronises the stream or the device.  A pointer the caller passes to a call (seeds,
+ *    actions, ...) is consumed on `stream` only and may be reused once `stream` has passed the call;
  *  - int return code: GE_OK or a negative GE_E_* value; no exceptions cross the ABI;
  *  - gfx950 only.
  */
@@ -55,7 +53,8 @@ enum {
                                                3 regenerated in this ge_step (next-step mode), 4 generation failed (see work_count[1]) */
 #define GE_REC_AUX_SHIFT   24               /* bits 24-31: ShortestPath / LongestPath with n <= 64: the destination node */
 #define GE_REC_TSTEP_SHIFT 32               /* bits 32-63: transitions executed by the slot since the last ge_reset (mod 2^32) */
-#define GE_SEED_DEPTH 3                     /* generator states kept per slot: the next GE_SEED_DEPTH episodes are pre-seeded */
+#define GE_SEED_DEPTH 3                     /* ring of generator states per slot: episode e lives in entry e mod 3; while a slot runs episode e the
+                                               entries of e+1 and e+2 are valid and the entry of e is being refilled with e+3 */
 
 /* Constructor kwargs of the reference env classes, plus batch geometry.
  * shortest_path.py:23, longest_path.py:26, steiner_tree.py:26, tsp.py:22,
@@ -122,12 +121,12 @@ typedef struct {
   uint64_t *target_bits;/* [B, W] SteinerTree: targets                                       */
   int32_t *counters;    /* [B, 2] taken count, edge count (Densest) / steps in episode (unused by the n <= 64 path kernel:
                                  an episode's length is the size of its visited set)          */
-  uint32_t *seed;       /* [B]  seed of the slot's current episode (written by the reset kernel only) */
-  int64_t *episode;     /* [B]  episode index k of the slot (written by the reset kernel only) */
+  uint32_t *seed;       /* [B]  seed of the slot's current episode (advanced by the feature kernel, the last kernel of a regeneration) */
+  int64_t *episode;     /* [B]  episode index k of the slot (likewise) */
   double *heuristic;    /* [B]  heuristic_solution of the current episode (is_eval_env)      */
-  uint32_t *mt_state;   /* [B, GE_SEED_DEPTH, 2, 624] MT19937 states (python stream, numpy stream) of the slot's next GE_SEED_DEPTH
-                                 episodes, episode e in ring entry e mod GE_SEED_DEPTH: seeded one lane per slot by a helper
-                                 kernel on the engine's side stream, GE_SEED_DEPTH episodes ahead of their use */
+  uint32_t *mt_state;   /* [B, GE_SEED_DEPTH, 2, 624] MT19937 states (python stream, numpy stream) of the slot's coming episodes, episode e
+                                 in ring entry e mod GE_SEED_DEPTH: seeded one lane per slot, two episodes before their use, by
+                                 seeding workgroups that ride in the reset launch of an earlier regeneration of the slot */
   uint64_t *aux_bits;   /* [B]  DistributionCenter with n <= 64: which rows of range_bits exist (else NULL) */
   /* --- outputs of the last step / reset */
   uint8_t *mask;        /* [B, A] info['mask'] as bool bytes                                 */
@@ -140,12 +139,9 @@ typedef struct {
   double *final_heur;   /* [B]  info['heuristic_solution'] where terminated (same-step autoreset: copied by the reset kernel
                                  before it overwrites `heuristic`)                             */
   int32_t *final_len;   /* [B]  episode length where terminated                              */
-  /* --- reset work queue (ring of GE_SEED_DEPTH generations, generation = ge_step count mod GE_SEED_DEPTH: the side stream
-   *     may still be reading generation g while the next steps fill g+1, g+2) */
-  int32_t *reset_list;  /* [GE_SEED_DEPTH, B]  step workgroup g (256 slots) lists its finished slots at [256g, 256g+count) */
-  int32_t *reset_count; /* [GE_SEED_DEPTH, ceil(B/256)] finished slots per step workgroup            */
-  uint32_t *seed_jobs;  /* [GE_SEED_DEPTH, B, 2] per regenerated slot, in queue order: {slot | ring entry << 28, seed} of the generator
-                                 state the side stream has to produce next (written by the reset kernel) */
+  /* --- reset work queue */
+  int32_t *reset_list;  /* [B]  step workgroup g (256 slots) lists its finished slots at [256g, 256g+count) */
+  int32_t *reset_count; /* [ceil(B/256)] finished slots per step workgroup, rewritten by every step    */
   int32_t *work_list;   /* [B]  slots the n<=64 feature fast path hands to the generic feature kernel  */
   int32_t *work_count;  /* [4]  [0] = entries in work_list; [1] = device error flags (bit 0: a G(n,m) rejection loop hit its
                                  round cap -- unseeded or corrupted generator state; the slot's status is 4) */
@@ -201,10 +197,10 @@ int ge_reset_pending(ge_engine *e, void *stream);
 int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
                     const int32_t *terminals, const uint32_t *seeds, void *stream);
 
-/* Checkpointing: the engine's state is its slabs plus ONE host-side number, the generation of the queue ring the next
- * ge_reset_pending consumes.  set < 0: return it; set >= 0: load it (after the caller has restored every slab of a
- * snapshot taken from an engine that had been reset; marks the engine as holding an episode and seeded). */
-int ge_queue_generation(ge_engine *e, int set);
+/* Checkpointing: the slabs are the whole state of an engine.  After restoring every slab from a snapshot of an engine that
+ * had been reset, tell the engine so (it then holds an episode and a seeded generator ring; the call-order guard of
+ * ge_step needs to know). */
+int ge_mark_restored(ge_engine *e);
 
 /* utils.vectorize_graph for the whole batch (utils.py:87-88): out [B, obs_len] float32. */
 int ge_vectorize(ge_engine *e, float *out, void *stream);

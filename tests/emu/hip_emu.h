@@ -25,6 +25,7 @@
 #define GE_KERNEL static void
 #define GE_KERNEL_LB(threads, waves_per_simd) static void
 #define GE_HOSTDEV inline
+#define GE_CONSTANT static const
 
 // ---- minimal HIP runtime surface used by ge_api
 typedef void *hipStream_t;
