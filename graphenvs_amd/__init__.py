@@ -18,7 +18,8 @@ __all__ = ["make", "make_vec", "GraphEnv", "VectorGraphEnv", "GraphBatch", "ENV_
 
 
 def register_with_gymnasium():
-    """Register the six ids with gymnasium when it is installed (graph_envs/__init__.py:9-56)."""
+    """Register the nine ids of the reference with gymnasium when it is installed (graph_envs/__init__.py:9-56): gymnasium.make(id,
+    **kwargs) then returns the single-env facade (GraphEnv), whose reset/step return what the reference's classes return."""
     from gymnasium.envs.registration import register
     for env_id in ENV_IDS:
         register(id=env_id, entry_point=lambda _id=env_id, **kw: make(_id, **kw))

@@ -62,7 +62,7 @@ class GeBuffers(C.Structure):
 
 # every symbol include/graphenvs.h declares
 SYMBOLS = [
-    "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_reset", "ge_step", "ge_step_only",
+    "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_ragged_table_bytes", "ge_create_ragged", "ge_reset", "ge_step", "ge_step_only",
     "ge_reset_pending", "ge_inject_state", "ge_mark_restored", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
     "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash",
 ]
@@ -133,6 +133,10 @@ def bind(lib):
     lib.ge_create.argtypes = [C.POINTER(GeConfig), C.POINTER(GeBuffers), C.POINTER(vp)]
     lib.ge_destroy.restype = C.c_int
     lib.ge_destroy.argtypes = [vp]
+    lib.ge_ragged_table_bytes.restype = C.c_int64
+    lib.ge_ragged_table_bytes.argtypes = [i32]
+    lib.ge_create_ragged.restype = C.c_int
+    lib.ge_create_ragged.argtypes = [C.POINTER(GeConfig), C.POINTER(GeBuffers), i32, vp, vp, vp, C.POINTER(vp)]
     lib.ge_reset.restype = C.c_int
     lib.ge_reset.argtypes = [vp, vp, vp]
     for name in ("ge_step", "ge_step_only"):

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "ge_params.h"
 #include "ge_platform.h"
@@ -17,10 +18,16 @@ struct ge_engine {
   ge_config cfg;
   int reset_grid;     // workgroups of the queue-mode reset launch
   int lds_bytes;
-  int feat_lds, feat_grid, feat_fast, gen_grid;  // structural-feature kernel launch geometry
+  int feat_lds, feat_grid, feat_fast, gen_grid, gen_lds;  // structural-feature kernel launch geometry
   hipEvent_t ev[4];
   bool have_events;
   int nseed;      // seeding workgroups at the head of the queue-mode reset launch (64 queued slots each)
+  // multi-class ("ragged") engine: P is then the engine-wide block (B = all slots, global queue / seed / episode / mt_state arrays,
+  // n / m / W = the widest class) and R names the device copy of the class table
+  int n_classes;
+  GeRagged R;
+  std::vector<GeParams> classes;  // host copy (ge_vectorize launches per class)
+  int feat64_pre_off, gen_pre_off;
   bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
   bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
 };
@@ -53,7 +60,7 @@ static const int kMaxLds = 160 * 1024;
     }                                                                                        \
   } while (0)
 
-static int derive(const ge_config *cfg, GeParams &P) {
+static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   if (!cfg) return fail(GE_E_BADARG, "null config");
   memset(&P, 0, sizeof(P));
   const int t = cfg->env_type, n = cfg->n_nodes, m = cfg->n_edges;
@@ -122,8 +129,8 @@ static int derive(const ge_config *cfg, GeParams &P) {
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
-  ge_make_lds(P);
-  ge_make_ldsf(P);
+  ge_make_lds(P, queue_B > 0 ? queue_B : P.B);
+  ge_make_ldsf(P, queue_B > 0 ? queue_B : P.B);
   if (P.lds.total > kMaxLds || P.ldsf.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
   return GE_OK;
 }
@@ -143,11 +150,17 @@ extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
 
 extern "C" int ge_destroy(ge_engine *e);
 
-extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out) {
-  if (!bufs || !out) return fail(GE_E_BADARG, "null argument");
-  GeParams P;
-  int rc = derive(cfg, P);
-  if (rc != GE_OK) return rc;
+// the multi-class engine is instantiated for the env ids of BASELINE config 5 (ShortestPath, DensestSubgraph, MaxIndependentSet)
+#define GE_FOR_RAGGED_ENV(env_type, stmt)                                                   \
+  do {                                                                                      \
+    switch (env_type) {                                                                     \
+      case GE_SHORTEST_PATH: { constexpr int ENV = GE_SHORTEST_PATH; stmt; break; }           \
+      case GE_DENSEST_SUBGRAPH: { constexpr int ENV = GE_DENSEST_SUBGRAPH; stmt; break; }     \
+      default: { constexpr int ENV = GE_MAX_INDEPENDENT_SET; stmt; break; }                   \
+    }                                                                                       \
+  } while (0)
+
+static int check_buffers(const GeParams &P, const ge_buffers *bufs) {
   const void *need[] = {bufs->x, bufs->edge_index, bufs->edge_attr, bufs->row_ptr, bufs->colw, bufs->scode, bufs->adj_bits, bufs->slot_rec,
                         bufs->terminals, bufs->node_bits, bufs->target_bits, bufs->counters, bufs->seed,
                         bufs->episode, bufs->heuristic, bufs->mt_state, bufs->mask, bufs->mask_bits, bufs->reward,
@@ -162,38 +175,125 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
   if (P.W == 1 && !bufs->node_rec) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec");
-  P.buf = *bufs;
-  ge_engine *e = new (std::nothrow) ge_engine();
-  if (!e) return fail(GE_E_BADARG, "out of host memory");
-  e->P = P; e->cfg = *cfg; e->lds_bytes = P.lds.total; e->have_events = false;
-  e->loaded = false; e->seeded = false;
-  int per_cu = kMaxLds / (P.lds.total > 0 ? P.lds.total : 1);
+  return GE_OK;
+}
+
+// launch geometry and LDS limits from e->P (uniform engine) or from the class table (multi-class engine); deletes e on failure
+static int finish_create(ge_engine *e, ge_engine **out) {
+  const GeParams &P = e->P;
+  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  const bool rg = e->n_classes > 0;
+  // ---- graph kernel
+  int reset_lds = P.lds.total, gen_lds = P.ldsf.total, f64_body = 0;
+  bool any64 = !rg && P.n <= 64 && !P.spatial;
+  if (!rg) f64_body = ge_f64_pre_off(P.E, P.env_type == GE_TSP, nblk);
+  for (const GeParams &C : e->classes) {
+    if (C.lds.total > reset_lds) reset_lds = C.lds.total;
+    if (C.ldsf.total > gen_lds) gen_lds = C.ldsf.total;
+    if (C.n <= 64) { any64 = true; const int b = ge_f64_pre_off(C.E, 0, nblk); if (b > f64_body) f64_body = b; }
+  }
+  if (rg && e->P.lds.pre != 0) { e->P.lds.pre = ge_align16(reset_lds); reset_lds = e->P.lds.pre + (nblk + 2) * 4; }  // prefix behind every class's scratch
+  e->lds_bytes = reset_lds;
+  if (reset_lds > kMaxLds || gen_lds > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS"); }
+  int per_cu = kMaxLds / (reset_lds > 0 ? reset_lds : 1);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
   e->reset_grid = 256 * per_cu;
   if (e->reset_grid > P.B) e->reset_grid = P.B;
   e->nseed = (e->reset_grid + 63) / 64;  // one seeding workgroup per 64 regenerating workgroups: the usual queue fits one round of both
-  if (P.lds.total > 64 * 1024) {
-    hipError_t hr = hipSuccess;
-    GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_reset<ENV>, P.lds.total));
-    if (hr != hipSuccess) { (void)ge_destroy(e); return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
+  hipError_t hr = hipSuccess;
+  if (reset_lds > 64 * 1024) {
+    if (rg) GE_FOR_RAGGED_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_reset<ENV, true>), reset_lds));
+    else GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_reset<ENV, false>), reset_lds));
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
-  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  e->feat_fast = (P.n <= 64 && !P.spatial) ? 1 : 0;  // float64 weights do not fit the fast path's LDS
-  e->feat_lds = e->feat_fast ? ge_f64_bytes(P.E, P.env_type == GE_TSP, nblk) : P.ldsf.total;
-  if (e->feat_lds > kMaxLds) { (void)ge_destroy(e); return fail(GE_E_TOOBIG, "feature kernel does not fit LDS"); }
-  if (P.ldsf.total > 64 * 1024) {
-    hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features, P.ldsf.total);
-    if (hr != hipSuccess) { (void)ge_destroy(e); return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the feature kernel"); }
+  // ---- feature kernels
+  e->feat_fast = any64 ? 1 : 0;  // (spatial TSP: float64 weights do not fit the fast path's LDS)
+  e->feat64_pre_off = ge_align16(f64_body + 8);
+  e->feat_lds = e->feat_fast ? e->feat64_pre_off + (nblk + 2) * 4 + 16 : gen_lds;
+  e->gen_lds = gen_lds;
+  e->gen_pre_off = P.ldsf.pre;
+  if (rg) { e->gen_pre_off = ge_align16(gen_lds); e->gen_lds = e->gen_pre_off + (nblk + 2) * 4; }
+  if (e->feat_lds > kMaxLds || e->gen_lds > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "feature kernel does not fit LDS"); }
+  if (e->gen_lds > 64 * 1024) {
+    hr = rg ? (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features<true>, e->gen_lds) : (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features<false>, e->gen_lds);
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the feature kernel"); }
   }
   if (e->feat_fast && e->feat_lds > 64 * 1024) {
-    hipError_t hr = (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features64, e->feat_lds);
-    if (hr != hipSuccess) { (void)ge_destroy(e); return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the n<=64 feature kernel"); }
+    hr = rg ? (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features64<true>, e->feat_lds) : (hipError_t)GE_SET_MAX_DYN_LDS(ge_k_features64<false>, e->feat_lds);
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the n<=64 feature kernel"); }
   }
-  { int per = kMaxLds / P.ldsf.total; if (per > 16) per = 16; if (per < 1) per = 1; e->gen_grid = 256 * per; if (e->gen_grid > P.B) e->gen_grid = P.B; }
+  { int per = kMaxLds / e->gen_lds; if (per > 16) per = 16; if (per < 1) per = 1; e->gen_grid = 256 * per; if (e->gen_grid > P.B) e->gen_grid = P.B; }
   { int per = kMaxLds / e->feat_lds; if (per > 16) per = 16; if (per < 1) per = 1; e->feat_grid = 256 * per; if (e->feat_grid > P.B) e->feat_grid = P.B; }
   *out = e;
   return GE_OK;
+}
+
+extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out) {
+  if (!bufs || !out) return fail(GE_E_BADARG, "null argument");
+  GeParams P;
+  int rc = derive(cfg, P);
+  if (rc != GE_OK) return rc;
+  rc = check_buffers(P, bufs);
+  if (rc != GE_OK) return rc;
+  P.buf = *bufs;
+  ge_engine *e = new (std::nothrow) ge_engine();
+  if (!e) return fail(GE_E_BADARG, "out of host memory");
+  e->P = P; e->cfg = *cfg; e->have_events = false;
+  e->loaded = false; e->seeded = false;
+  e->n_classes = 0; memset(&e->R, 0, sizeof(e->R));
+  return finish_create(e, out);
+}
+
+extern "C" int64_t ge_ragged_table_bytes(int32_t n_classes) { return (int64_t)sizeof(GeParams) * (n_classes > 0 ? n_classes : 0); }
+
+extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, int32_t n_classes, void *class_table,
+                                int32_t *slot_class, int32_t *class_start, ge_engine **out) {
+  if (!cfgs || !bufs || !out || !class_table || !slot_class || !class_start || n_classes < 1) return fail(GE_E_BADARG, "null argument");
+  const int t = cfgs[0].env_type;
+  if (t != GE_SHORTEST_PATH && t != GE_DENSEST_SUBGRAPH && t != GE_MAX_INDEPENDENT_SET)
+    return fail(GE_E_UNSUPPORTED, "the multi-class engine is built for ShortestPath, DensestSubgraph and MaxIndependentSet (BASELINE config 5)");
+  int64_t total = 0;
+  for (int c = 0; c < n_classes; c++) total += cfgs[c].num_envs;
+  if (total > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
+  ge_engine *e = new (std::nothrow) ge_engine();
+  if (!e) return fail(GE_E_BADARG, "out of host memory");
+  e->classes.resize(n_classes);
+  std::vector<int32_t> start(n_classes + 1, 0), cls_of((size_t)total);
+  int wmin = 8, widest = 0;
+  for (int c = 0; c < n_classes; c++) {
+    GeParams &C = e->classes[c];
+    int rc = derive(&cfgs[c], C, (int)total);
+    if (rc == GE_OK) rc = check_buffers(C, &bufs[c]);
+    if (rc == GE_OK && (cfgs[c].env_type != t || cfgs[c].autoreset != cfgs[0].autoreset || cfgs[c].seed_stride != cfgs[0].seed_stride))
+      rc = fail(GE_E_BADARG, "the classes of a multi-class engine share env_type, autoreset and seed_stride");
+    if (rc == GE_OK && (cfgs[c].env_index_base != cfgs[0].env_index_base + start[c] || bufs[c].seed != bufs[0].seed + start[c] ||
+                        bufs[c].episode != bufs[0].episode + start[c] || bufs[c].mt_state != bufs[0].mt_state + (int64_t)start[c] * GE_SEED_DEPTH * 2 * GE_MT_N))
+      rc = fail(GE_E_BADARG, "classes follow one another in slot order: env_index_base, seed, episode and mt_state of class c start at its first global slot");
+    if (rc != GE_OK) { delete e; return rc; }
+    C.buf = bufs[c];
+    C.feat_parts = 1;
+    start[c + 1] = start[c] + cfgs[c].num_envs;
+    for (int i = start[c]; i < start[c + 1]; i++) cls_of[(size_t)i] = c;
+    if (C.n > 64 && C.ldsf.waves < wmin) wmin = C.ldsf.waves;
+    if (C.n > e->classes[widest].n) widest = c;
+  }
+  for (GeParams &C : e->classes) ge_make_ldsf(C, (int)total, wmin);  // one launch geometry of the generic feature kernel for every class
+  // engine-wide block: the widest class's geometry (LDS stage of the step kernel), all slots, the global arrays of class 0
+  e->P = e->classes[widest];
+  e->P.B = (int32_t)total;
+  e->P.buf = bufs[0];
+  e->P.env_index_base = cfgs[0].env_index_base;
+  e->cfg = cfgs[0]; e->cfg.num_envs = (int32_t)total;
+  e->have_events = false; e->loaded = false; e->seeded = false;
+  e->n_classes = n_classes;
+  if (hipMemcpy(class_table, e->classes.data(), sizeof(GeParams) * (size_t)n_classes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(slot_class, cls_of.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(class_start, start.data(), sizeof(int32_t) * (size_t)(n_classes + 1), hipMemcpyHostToDevice) != hipSuccess) {
+    delete e; return fail(GE_E_LAUNCH, "cannot copy the class table to the device");
+  }
+  e->R.classes = (const GeParams *)class_table; e->R.slot_class = slot_class; e->R.class_start = class_start; e->R.n_classes = n_classes;
+  return finish_create(e, out);
 }
 
 extern "C" int ge_destroy(ge_engine *e) {
@@ -220,23 +320,29 @@ static int launch_seed(ge_engine *e, const uint32_t *seeds, int jlo, void *strea
 
 static int launch_features(ge_engine *e, int mode, void *stream) {
   int rc = GE_OK;
+  const bool rg = e->n_classes > 0;
   int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);
+  const int gen_threads = GE_WAVE * (rg ? e->classes[0].ldsf.waves : e->P.ldsf.waves);
   if (e->feat_fast) {
-    GE_LAUNCH(ge_k_features64, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, mode);
+    if (rg) GE_LAUNCH(ge_k_features64<true>, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, e->R, mode, e->feat64_pre_off);
+    else GE_LAUNCH(ge_k_features64<false>, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, e->R, mode, e->feat64_pre_off);
     rc = check_launch("feature kernel (n <= 64)");
     if (rc != GE_OK) return rc;
-    int g2 = e->gen_grid < 64 ? e->gen_grid : 64;  // normally an empty list
-    GE_LAUNCH(ge_k_features, g2, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total, stream, e->P, (int)GE_FEAT_LIST);
+    // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64
+    int g2 = e->gen_grid < 64 && !rg ? e->gen_grid : (rg ? e->gen_grid : 64);
+    if (rg) GE_LAUNCH(ge_k_features<true>, g2, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
+    else GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
     return check_launch("feature kernel (fallback list)");
   }
   {
     int64_t want = (int64_t)fgrid * e->P.feat_parts;
     if (mode == GE_RESET_QUEUE && want > 4096) want = 4096;  // queue mode: the list is short, workgroups stride over it
     if (want > 65535 * 16) want = 65535 * 16;
-    GE_LAUNCH(ge_k_features, (int)want, GE_WAVE * e->P.ldsf.waves, e->feat_lds, stream, e->P, mode);
+    if (rg) GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);
+    else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);
   }
   rc = check_launch("feature kernel");
-  if (rc != GE_OK || e->P.feat_parts == 1) return rc;
+  if (rc != GE_OK || e->P.feat_parts == 1 || rg) return rc;
   {
     size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
     int64_t items = (int64_t)(mode == GE_RESET_QUEUE ? 4096 : e->P.B) * e->P.n;
@@ -255,7 +361,8 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
   else if (mode == GE_RESET_INJECT && inj.seeds) rc = launch_seed(e, inj.seeds, 1, stream);  // the injected episode needs no states of its own
   if (rc != GE_OK) return rc;
   int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid + e->nseed : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  GE_FOR_ENV(e->P.env_type, GE_LAUNCH(ge_k_reset<ENV>, grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, seeds, mode, inj, e->nseed));
+  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
   rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;
   if (mode != GE_RESET_INJECT) rc = launch_features(e, mode, stream);
@@ -282,6 +389,7 @@ extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
 extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
                                const int32_t *terminals, const uint32_t *seeds, void *stream) {
   if (!e || !links || !wcode || !x) return fail(GE_E_BADARG, "null argument");
+  if (e->n_classes > 0) return fail(GE_E_UNSUPPORTED, "ge_inject_state is not built for the multi-class engine (inject into uniform engines)");
   const int t = e->P.env_type;
   if ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER ||
        t == GE_PERISHABLE_DELIVERY) && !terminals)
@@ -301,7 +409,7 @@ static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P
 extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream);
 
 static bool path64(const ge_engine *e) {
-  return (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1 && e->P.parenting < 2;
+  return e->n_classes == 0 && (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1 && e->P.parenting < 2;
 }
 
 // call-order guard (the reference raises in the same situations): stepping needs an episode in the slots, and autoreset needs a
@@ -322,8 +430,9 @@ extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) 
     if (rc != GE_OK) return rc;
   }
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0));
+  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions, (uint64_t)0));
+  else if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions, (uint64_t)0));
   return check_launch("step kernel");
 }
 
@@ -338,8 +447,9 @@ static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch,
     return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
   }
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (path64(e)) GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed));
+  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, (const int64_t *)nullptr, policy_seed));
+  else if (path64(e)) GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed);
+  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, (const int64_t *)nullptr, policy_seed));
   return check_launch("fused sample+step kernel");
 }
 
@@ -376,6 +486,17 @@ extern "C" int ge_mark_restored(ge_engine *e) {
 
 extern "C" int ge_vectorize(ge_engine *e, float *out, void *stream) {
   if (!e || !out) return fail(GE_E_BADARG, "null argument");
+  if (e->n_classes > 0) {  // multi-class engine: the classes' flat vectors follow one another, class after class
+    for (const GeParams &C : e->classes) {
+      const int64_t Lc = (int64_t)C.n * C.F + (int64_t)C.E * C.Fe + 2 * (int64_t)C.E, tot = (int64_t)C.B * Lc;
+      int64_t blocks = (tot + 255) / 256; if (blocks > 256 * 32) blocks = 256 * 32;
+      GE_LAUNCH(ge_k_vectorize, (int)blocks, 256, 0, stream, C, out);
+      int rc = check_launch("vectorize kernel");
+      if (rc != GE_OK) return rc;
+      out += tot;
+    }
+    return GE_OK;
+  }
   int64_t L = (int64_t)e->P.n * e->P.F + (int64_t)e->P.E * e->P.Fe + 2 * (int64_t)e->P.E;
   int64_t total = (int64_t)e->P.B * L;
   int64_t blocks = (total + 255) / 256;
@@ -387,7 +508,8 @@ extern "C" int ge_vectorize(ge_engine *e, float *out, void *stream) {
 extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream) {
   if (!e || !actions) return fail(GE_E_BADARG, "null argument");
   int grid = (e->P.B + 255) / 256;
-  GE_LAUNCH(ge_k_sample, grid, 256, 0, stream, e->P, policy_seed, actions);
+  if (e->n_classes > 0) GE_LAUNCH(ge_k_sample<true>, grid, 256, 0, stream, e->P, e->R, policy_seed, actions);
+  else GE_LAUNCH(ge_k_sample<false>, grid, 256, 0, stream, e->P, e->R, policy_seed, actions);
   return check_launch("sample kernel");
 }
 
@@ -450,9 +572,9 @@ extern "C" int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k
 extern "C" int ge_debug_occupancy(ge_engine *e, int *out4) {
   if (!e || !out4) return GE_E_BADARG;
   int a = -1, b = -1, c = -1, d = -1;
-  GE_FOR_ENV(e->P.env_type, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ge_k_reset<ENV>, GE_RESET_THREADS, e->lds_bytes));
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ge_k_features64, GE_F64_THREADS, e->feat_lds);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ge_k_features, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total);
+  GE_FOR_ENV(e->P.env_type, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (ge_k_reset<ENV, false>), GE_RESET_THREADS, e->lds_bytes));
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ge_k_features64<false>, GE_F64_THREADS, e->feat_lds);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ge_k_features<false>, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total);
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, ge_k_step_path64<true>, GE_STEP_BLOCK, step_lds(e));
   out4[0] = a; out4[1] = b; out4[2] = c; out4[3] = d;
   return GE_OK;

@@ -200,7 +200,8 @@ GE_DEV GeF64 ge_carve_f64(int E, int tsp) {
   c.scode = (uint8_t *)(((uintptr_t)s + 15) & ~(uintptr_t)15);
   return c;
 }
-GE_DEV int *ge_f64_pre(int E, int tsp, int nblk) { return (int *)(ge_dyn_smem() + ge_f64_bytes(E, tsp, nblk) - (nblk + 2) * 4 - 8); }
+// byte offset of the queue prefix (nblk + 1 ints) and the overflow flag inside the dynamic LDS of the n <= 64 feature kernel
+GE_HOSTDEV int ge_f64_pre_off(int E, int tsp, int nblk) { return ge_f64_bytes(E, tsp, nblk) - (nblk + 2) * 4 - 8; }
 
 // 320-thread workgroup.  Waves 0-3 are the walkers: the Brandes walks are chains of LDS round trips, so the 64
 // sources are spread over four waves (16 quads each) on the CU's four SIMDs.  Wave 4 is the node wave (one lane
@@ -220,7 +221,7 @@ typedef uint64_t ge_slice_t;  // one lane per source: the lane serves every targ
 typedef uint32_t ge_slice_t;
 #define GE_SLICE_CTZ(x) ((int)__builtin_ctz(x))
 #endif
-GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
+GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32_t *work_count, int32_t *work_list, int env_global) {
   const int tid = ge_tid_fresh();
   const bool node_wave = tid >= GE_F64_WALKERS;
   const int lane = tid - GE_F64_WALKERS;  // node index inside the node wave
@@ -374,7 +375,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
   ge_sync();
   GE_STAMP(14);
   if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
-    if (tid == 0) { int k = atomicAdd(&G.work_count[0], 1); G.work_list[k] = env; }
+    if (tid == 0) { int k = atomicAdd(&work_count[0], 1); work_list[k] = env_global; }
     ge_sync();
     return;
   }
@@ -398,9 +399,14 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag) {
 
 enum { GE_FEAT_LIST = 3 };  // slots from work_list (fallback of the fast path)
 
-// mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list
-GE_KERNEL ge_k_features(GeParams P, int mode) {
-  int *pre = (int *)(ge_dyn_smem() + P.ldsf.pre);
+// the class of a global slot (multi-class engine), as a wave-uniform value
+GE_DEV int ge_slot_class(const GeRagged &R, int env) { return (int)ge_uniform_u32((uint32_t)R.slot_class[env]); }
+
+// mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list.  pre_off: byte
+// offset of the queue prefix inside the dynamic LDS (behind the largest class's scratch in a multi-class engine).
+template <bool RAGGED>
+GE_KERNEL ge_k_features(GeParams P, GeRagged R, int mode, int pre_off) {
+  int *pre = (int *)(ge_dyn_smem() + pre_off);
   int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
   if (mode == GE_RESET_QUEUE) {
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
@@ -412,7 +418,12 @@ GE_KERNEL ge_k_features(GeParams P, int mode) {
     const int item = q / nparts;
     const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
     if (mode == GE_RESET_QUEUE && q % nparts == 0 && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
-    ge_features_generic_env(P, env, q % nparts, nparts);
+    if constexpr (RAGGED) {
+      const int cls = ge_slot_class(R, env);
+      ge_features_generic_env(R.classes[cls], env - R.class_start[cls], 0, 1);
+    } else {
+      ge_features_generic_env(P, env, q % nparts, nparts);
+    }
   }
 }
 
@@ -437,9 +448,11 @@ GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
   }
 }
 
-GE_KERNEL ge_k_features64(GeParams P, int mode) {
+// n <= 64 fast path over every slot / the queue.  Multi-class engine: a slot of a class with n > 64 goes straight to work_list.
+template <bool RAGGED>
+GE_KERNEL ge_k_features64(GeParams P, GeRagged R, int mode, int pre_off) {
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  int *pre = ge_f64_pre(P.E, P.env_type == GE_TSP, nblk);
+  int *pre = (int *)(ge_dyn_smem() + pre_off);
   int count = P.B;
   if (mode == GE_RESET_QUEUE) {  // the prefix scan is one wave wide
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
@@ -449,6 +462,16 @@ GE_KERNEL ge_k_features64(GeParams P, int mode) {
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
     const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
     if (mode == GE_RESET_QUEUE && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
-    ge_features64_env(P, env, pre + nblk + 1);
+    if constexpr (RAGGED) {
+      const int cls = ge_slot_class(R, env);
+      const GeParams &C = R.classes[cls];
+      if (C.n > 64) {  // uniform: the generic kernel takes the slot (global id)
+        if (ge_tid() == 0) { int k = atomicAdd(&P.buf.work_count[0], 1); P.buf.work_list[k] = env; }
+        continue;
+      }
+      ge_features64_env(C, env - R.class_start[cls], pre + nblk + 1, P.buf.work_count, P.buf.work_list, env);
+    } else {
+      ge_features64_env(P, env, pre + nblk + 1, P.buf.work_count, P.buf.work_list, env);
+    }
   }
 }

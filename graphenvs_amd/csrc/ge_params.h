@@ -66,18 +66,34 @@ struct GeParams {
   GeLdsF ldsf;
 };
 
+// Multi-class ("ragged") engine, BASELINE config 5: slots of different (n, m) stepped by ONE launch sequence.  A size class is a
+// uniform sub-engine with its own GeParams (geometry, LDS carves, slab segments); every kernel maps a global slot to (class, local
+// slot) and runs the class's code path.  Per-slot scalars, generator states and the reset queue are global arrays in slot order.
+struct GeRagged {
+  const GeParams *classes;     // [n_classes] device copy of the class table
+  const int32_t *slot_class;   // [B_total]
+  const int32_t *class_start;  // [n_classes + 1] first global slot of every class
+  int32_t n_classes;
+};
+
 static inline int ge_align16(int v) { return (v + 15) & ~15; }
 
-static inline void ge_make_lds(GeParams &P) {
+// queue_B: slots of the whole engine (the reset queue's prefix array is sized by it; == P.B for a uniform engine)
+static inline void ge_make_lds(GeParams &P, int queue_B) {
   GeLds &L = P.lds;
   int o = 0;
   auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
   L.mt = take(GE_MT_N * 4);
   L.mt2 = take(GE_MT_N * 4);
-  { int nb = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 16; if (P.m > nb) nb = P.m; if (P.n > nb) nb = P.n;
+  { // the dense n x n nibble matrix of delay codes is only drawn by the envs whose weights are delay[u, v] (ge_numpy_wave); TSP,
+    // MaxIndependentSet and DensestSubgraph draw a byte list of m / n codes (or nothing)
+    const bool matrix_env = P.env_type == GE_SHORTEST_PATH || P.env_type == GE_LONGEST_PATH || P.env_type == GE_STEINER_TREE ||
+                            P.env_type == GE_MULTICAST_ROUTING || P.env_type == GE_DISTRIBUTION_CENTER || P.env_type == GE_PERISHABLE_DELIVERY;
+    const int matrix = (P.np_early && matrix_env && P.weighted) ? ((P.n * P.n + 7) / 8) * 4 : 0;
+    int nb = matrix > 16 ? matrix : 16; if (P.m > nb) nb = P.m; if (P.n > nb) nb = P.n;
     if (P.spatial && 32 * P.n > nb) nb = 32 * P.n;  // raw draws u32[4n] + coordinates f64[2n]
     P.cost_off = 0;
-    if (P.env_type == GE_DISTRIBUTION_CENTER) { P.cost_off = P.np_early ? ((P.n * P.n + 7) / 8) * 4 : 0; if (P.cost_off + P.n > nb) nb = P.cost_off + P.n; }
+    if (P.env_type == GE_DISTRIBUTION_CENTER) { P.cost_off = matrix; if (P.cost_off + P.n > nb) nb = P.cost_off + P.n; }
     L.wm = take(nb); }
   L.abits = take(P.n * P.W * 8);
   L.elist = take((P.m > 0 ? P.m : 1) * 4);
@@ -95,12 +111,13 @@ static inline void ge_make_lds(GeParams &P) {
   L.dcs = (P.env_type == GE_DISTRIBUTION_CENTER && P.n <= 64) ? take(P.n * GE_DC_LANES * 8 + 64 * GE_DC_LANES) : 0;
   L.kou = (P.env_type == GE_STEINER_TREE && P.is_eval && P.n_dests > 1 && P.n_dests < P.n - 1) ? take(2 * P.n * P.W * 8 + P.T * 16) : 0;
   // the queue prefix is only needed while a workgroup looks up its slot: it overlays the scratch that follows
-  { int pb = ((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4; L.pre = L.mt; if (pb > GE_MT_N * 8) { L.pre = take(pb); } }
+  { int pb = ((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4; L.pre = L.mt; if (pb > GE_MT_N * 8) { L.pre = take(pb); } }
   if (o < GE_SEED_LDS_BYTES) o = GE_SEED_LDS_BYTES;  // the seeding workgroups of the queue-mode launch use the same allocation
   L.total = o;
 }
 
-static inline void ge_make_ldsf(GeParams &P) {
+// force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry for every class)
+static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0) {
   GeLdsF &L = P.ldsf;
   int o = 0;
   auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
@@ -111,7 +128,7 @@ static inline void ge_make_ldsf(GeParams &P) {
   // the wave count fixes the order of the float64 betweenness partial sums: it is decided from the graph geometry alone (with a
   // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
   const int shared = o + 1024 + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
-  L.pre = take(((P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
+  L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
   int waves = (160 * 1024 / 2 - shared) / (per_wave > 0 ? per_wave : 1);  // aim at two workgroups per CU
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
@@ -119,6 +136,7 @@ static inline void ge_make_ldsf(GeParams &P) {
   // complete graph on all nodes (TSP config 3): Brandes is skipped, the workgroup is the pagerank over n rows of n-1 entries --
   // as many waves as fit one workgroup per CU
   if (P.complete && P.ng == P.n && P.n > 64) { waves = (160 * 1024 - shared) / (per_wave > 0 ? per_wave : 1); if (waves > 8) waves = 8; if (waves < 1) waves = 1; }
+  if (force_waves > 0) waves = force_waves;
   L.waves = waves;
   L.dist = take(waves * P.n * 4);
   L.f64a = take((6 + 4 * waves) * P.n * 8);

@@ -1589,8 +1589,10 @@ GE_DEV void ge_advance_episode(const GeParams &P, int env) {
 // Queue mode: the first `nseed` workgroups of the launch are seeding workgroups (64 queued slots each): they refill the ring
 // entry the slot's PREVIOUS regeneration consumed with the states of the episode GE_SEED_DEPTH ahead of the one that just
 // ended, while the other workgroups regenerate the queued slots from the entries seeded long ago -- no second stream, no event.
-template <int ENV>
-GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, const uint32_t *seeds, int mode, GeInject inj, int nseed) {
+// RAGGED (multi-class engine): P is the engine-wide parameter block (B = all slots; queue, seed[], episode[], mt_state are global
+// arrays in slot order) and every workgroup looks up the class of its slot: R.classes[class] is that class's uniform sub-engine.
+template <int ENV, bool RAGGED>
+GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, GeRagged R, const uint32_t *seeds, int mode, GeInject inj, int nseed) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
@@ -1625,6 +1627,12 @@ GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, c
       env = ge_queue_slot(P, pre, q);
       ge_sync();  // every thread has its slot before the scratch is reused
     }
-    ge_reset_env<ENV>(P, env, seeds, mode, inj);
+    if constexpr (RAGGED) {
+      const int cls = (int)ge_uniform_u32((uint32_t)R.slot_class[env]);
+      const int lo = R.class_start[cls];
+      ge_reset_env<ENV>(R.classes[cls], env - lo, seeds ? seeds + lo : seeds, mode, inj);
+    } else {
+      ge_reset_env<ENV>(P, env, seeds, mode, inj);
+    }
   }
 }

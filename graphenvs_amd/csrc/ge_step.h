@@ -100,25 +100,33 @@ GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
   return -1;
 }
 
-// SAMPLE: the device policy is evaluated here (one launch per rollout step) and the action is also written to actions_out
-template <int ENV, bool SAMPLE>
-GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
-  const ge_buffers &G = P.buf;
+// SAMPLE: the device policy is evaluated here (one launch per rollout step) and the action is also written to actions_out.
+// RAGGED (multi-class engine): PG is the engine-wide block (B = all slots, the reset queue); every thread looks up its slot's class
+// and runs that class's transition on the class-local slot index -- P then lives in memory (per-lane loads), which the reset-
+// dominated ragged workloads can afford.  Mask bytes are written by the slot's own thread (the classes' mask widths differ).
+template <int ENV, bool SAMPLE, bool RAGGED>
+GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t policy_seed) {
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
-  const int i = i0 + tid;
+  const int ig = i0 + tid;  // global slot
+  int cls = 0, lo = 0;
+  if constexpr (RAGGED) { if (ig < PG.B) { cls = R.slot_class[ig]; lo = R.class_start[cls]; } }
+  const GeParams &P = RAGGED ? R.classes[cls] : PG;
+  const ge_buffers &G = P.buf;
+  const int i = ig - lo;    // slot inside its class (== ig in a uniform engine)
   const int n = P.n, W = P.W, F = P.F, A = P.A, AW = P.AW;
+  const int WS = RAGGED ? PG.W : W;  // words per thread in the LDS stage (the widest class)
   constexpr int t = ENV;  // one instantiation per env type: the simple envs do not carry the others' registers
-  uint64_t *stage = (uint64_t *)ge_dyn_smem();  // [blockDim][W] new node masks (node-action envs)
+  uint64_t *stage = (uint64_t *)ge_dyn_smem();  // [blockDim][WS] new node masks (node-action envs)
   const bool edge_mask = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   bool wrote_mask = false;  // this slot's node mask changed and sits in `stage`
 
   bool want_reset = false;
 
-  if (i < P.B) {
+  if (ig < PG.B) {
     const int64_t nbase = (int64_t)i * n;
     int64_t a64;
-    if (SAMPLE) { a64 = ge_policy_pick(P, i, policy_seed); if (G.actions_out) G.actions_out[i] = a64; } else a64 = actions[i];
+    if (SAMPLE) { a64 = ge_policy_pick(P, i, policy_seed); if (PG.buf.actions_out) PG.buf.actions_out[ig] = a64; } else a64 = actions[ig];
     const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
     double cost = ge_u64_as_f64(rec.x);
     const int st = ge_rec_status(rec.y);
@@ -168,7 +176,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             uint64_t nm = (lp && P.parenting == 0) ? ge_full_word(A, w) : (G.adj_bits[(nbase + a) * W + w] & ~vb);
             if (prune) { nm &= R[w]; if (P.parenting == 3 && n_alive <= n / 3) nm |= alive[w]; }
-            stage[tid * W + w] = nm; any |= nm;
+            stage[tid * WS + w] = nm; any |= nm;
           }
           wrote_mask = !(lp && P.parenting == 0);
           if (!done && !any) { done = 1; solved = 0; reward = lp ? -2.0 * n : -(double)n; }
@@ -197,7 +205,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
             uint64_t nm = G.adj_bits[(nbase + a) * W + w] & ~vb;
             if (taken < n - 1 && w == 0) nm &= ~1ull;  // start only once everything else is taken (tsp.py:178-179)
-            stage[tid * W + w] = nm; any |= nm;
+            stage[tid * WS + w] = nm; any |= nm;
           }
           if (P.parenting >= 2 && any) {  // tsp.py:181-194: a move must leave the untaken nodes (start excluded) connected
             uint64_t alive[GE_MAXW], R[GE_MAXW];
@@ -210,7 +218,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
             any = 0;
             bool stop = false;
             for (int w = 0; w < W; w++) {
-              uint64_t nm = stage[tid * W + w];
+              uint64_t nm = stage[tid * WS + w];
               for (uint64_t cnd = nm; cnd && !stop; cnd &= cnd - 1) {
                 int v = w * 64 + ge_ctz64(cnd);
                 if (v == start) continue;
@@ -222,7 +230,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
                 for (int w2 = 0; w2 < W; w2++) reached += ge_popc64(R[w2]);
                 if (reached != n_alive - 1) nm &= ~(1ull << (v & 63));
               }
-              stage[tid * W + w] = nm; any |= nm;
+              stage[tid * WS + w] = nm; any |= nm;
             }
           }
           wrote_mask = true;
@@ -363,7 +371,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
           for (int w = 0; w < W; w++) {
             uint64_t nm = G.adj_bits[(nbase + now) * W + w];
             if (waits_here && (now >> 6) == w) nm |= 1ull << (now & 63);
-            stage[tid * W + w] = nm;
+            stage[tid * WS + w] = nm;
           }
           wrote_mask = true;
           break;
@@ -384,15 +392,15 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
             for (uint64_t f = fresh; f; f &= f - 1) G.x[(nbase + w * 64 + ge_ctz64(f)) * F + 3] = 1.f;
             r += (float)ge_popc64(fresh & tg[w]);
             left |= tg[w] & ~(old | Ra[w]);
-            stage[tid * W + w] = (P.parenting == 2) ? 0ull : ge_full_word(A, w);
+            stage[tid * WS + w] = (P.parenting == 2) ? 0ull : ge_full_word(A, w);
           }
           if (P.parenting == 2)  // union of the ranges of the targets still uncovered (distribution_center.py:133-135)
             for (int w0 = 0; w0 < W; w0++)
               for (uint64_t tl = tg[w0] & ~cov[w0]; tl; tl &= tl - 1) {
                 const uint64_t *Rt = G.range_bits + (nbase + w0 * 64 + ge_ctz64(tl)) * W;
-                for (int w = 0; w < W; w++) stage[tid * W + w] |= Rt[w];
+                for (int w = 0; w < W; w++) stage[tid * WS + w] |= Rt[w];
               }
-          for (int w = 0; w < W; w++) stage[tid * W + w] &= ~taken[w];
+          for (int w = 0; w < W; w++) stage[tid * WS + w] &= ~taken[w];
           wrote_mask = true;
           reward = (double)r;
           if (!left) { done = 1; solved = 1; }
@@ -421,7 +429,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
               G.target_bits[(int64_t)i * W + w] = un;
               nm = un & ~vb;
             }
-            stage[tid * W + w] = nm; any |= nm;
+            stage[tid * WS + w] = nm; any |= nm;
           }
           wrote_mask = true;
           if ((double)k == P.n_choices) done = 1;
@@ -440,7 +448,7 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
             uint64_t nm = ge_full_word(A, w) & ~vb;
-            stage[tid * W + w] = nm; any |= nm;
+            stage[tid * WS + w] = nm; any |= nm;
           }
           wrote_mask = true;
           if (!any) { done = 1; solved = 1; }
@@ -472,13 +480,19 @@ GE_KERNEL ge_k_step(GeParams P, const int64_t *actions, uint64_t policy_seed) {
       }
     }
     if (acted || st == 3) ((ulonglong2 *)G.slot_rec)[i] = make_ulonglong2(ge_f64_as_u64(cost), ge_rec_make(head_out, st_out, ge_rec_aux(rec.y), ts));
-    if (wrote_mask && !edge_mask) for (int w = 0; w < W; w++) G.mask_bits[(int64_t)i * AW + w] = stage[tid * W + w];
+    if (wrote_mask && !edge_mask) for (int w = 0; w < W; w++) G.mask_bits[(int64_t)i * AW + w] = stage[tid * WS + w];
+    if constexpr (RAGGED) {  // the slot's own thread expands its mask words to bool bytes
+      if (wrote_mask && !edge_mask) {
+        uint8_t *out = G.mask + (int64_t)i * A;
+        for (int v = 0; v < A; v++) out[v] = (uint8_t)((stage[tid * WS + (v >> 6)] >> (v & 63)) & 1ull);
+      }
+    }
   }
 
-  uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * W);
+  uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * WS);
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
-  if (edge_mask) return;  // SteinerTree updates its [B, 2m] mask incrementally above
+  ge_enqueue_reset(PG, (int *)(flag + ge_bdim()), i0, ig, tid, want_reset);  // contains the barrier; global slot ids
+  if (edge_mask || RAGGED) return;  // SteinerTree updates its [B, 2m] mask incrementally above
   // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
   if (nb <= 0) return;
@@ -686,10 +700,12 @@ GE_KERNEL ge_k_dc_range(GeParams P, const int64_t *actions) {
   P.buf.aux_bits[i] = have | (1ull << a);
 }
 
-GE_KERNEL ge_k_sample(GeParams P, uint64_t policy_seed, int64_t *actions) {
+template <bool RAGGED>
+GE_KERNEL ge_k_sample(GeParams P, GeRagged R, uint64_t policy_seed, int64_t *actions) {
   int i = ge_bid() * ge_bdim() + ge_tid();
   if (i >= P.B) return;
-  actions[i] = ge_policy_pick(P, i, policy_seed);
+  if constexpr (RAGGED) { const int cls = R.slot_class[i]; actions[i] = ge_policy_pick(R.classes[cls], i - R.class_start[cls], policy_seed); }
+  else actions[i] = ge_policy_pick(P, i, policy_seed);
 }
 
 // utils.vectorize_graph for every slot (utils.py:87-88): [x.ravel | edge_attr.ravel | links.ravel] as f32

@@ -1,86 +1,142 @@
-"""Ragged and mixed batches (BASELINE config 5): env instances of different (n_nodes, n_edges) — and different
-env ids — stepped together.  Every reference env instance has a fixed geometry (constructor kwargs), so a ragged
-batch is a set of size classes.  Each class is one uniform engine; the classes of one env id share ONE set of PyG
-slabs (x, edge_index, edge_attr: variable-size CSR packing, node ids offset per class through
-``ge_config.node_id_base`` / ``edge_row_stride``), so the policy sees a single ragged ``Batch``.  One launch
-sequence per class ("one launch per env type")."""
+"""Ragged and mixed batches (BASELINE config 5): env instances of different (n_nodes, n_edges) -- and different env ids --
+stepped together.  Every reference env instance has a fixed geometry (constructor kwargs), so a ragged batch is a list of size
+classes.  ``RaggedVectorEnv`` is ONE multi-class engine per env id (``ge_create_ragged``): every kernel launch covers all classes
+(a workgroup looks up the class of its slot), the classes share one set of PyG slabs (x, edge_index, edge_attr: variable-size CSR
+packing, node ids offset per class through ``ge_config.node_id_base`` / ``edge_row_stride``), and the per-slot outputs are single
+tensors over all slots.  ``MixedVectorEnv`` puts env ids side by side: one launch sequence per env id."""
+import ctypes as C
+
 import numpy as np
 import torch
 
+from . import _lib
 from .vector_env import GraphBatch, VectorGraphEnv
+
+# per-slot arrays kept engine-wide (class c owns rows [start_c, start_c + B_c))
+_GLOBAL = dict(seed=((), torch.int32), episode=((), torch.int64), mt_state=((_lib.SEED_DEPTH, 2, 624), torch.int32),
+               slot_rec=((2,), torch.int64), heuristic=((), torch.float64), reward=((), torch.float64),
+               terminated=((), torch.uint8), invalid=((), torch.uint8), solved=((), torch.int8),
+               final_cost=((), torch.float64), final_heur=((), torch.float64), final_len=((), torch.int32),
+               counters=((2,), torch.int32))
 
 
 class RaggedVectorEnv:
-    """One env id, several size classes: ``sizes = [(num_envs, n_nodes, n_edges), ...]``.  Slots are numbered class
-    after class; slot g runs seed (seed + g) like a uniform engine."""
+    """One env id, several size classes: ``sizes = [(num_envs, n_nodes, n_edges), ...]``.  Slots are numbered class after class;
+    slot g runs seed (seed + g) like a uniform engine.  ``classes[c]`` are views of class c (``.mask`` [B_c, A_c], ``.t[...]``)."""
 
-    def __init__(self, env_id, sizes, device="cuda", env_index_base=0, seed_stride=None, _library=None, **kwargs):
+    def __init__(self, env_id, sizes, device="cuda", env_index_base=0, seed_stride=None, autoreset=True, _library=None, **kwargs):
         self.env_id, self.device = env_id, torch.device(device)
         self.sizes = [(int(b), int(n), int(m)) for b, n, m in sizes]
-        self.num_envs = sum(b for b, _, _ in self.sizes)
-        stride = int(seed_stride) if seed_stride is not None else self.num_envs
-        probe = VectorGraphEnv(env_id, 1, self.sizes[0][1], self.sizes[0][2], device=device, _library=_library, **kwargs)
-        F, Fe = probe.F, probe.Fe
-        probe.close()
+        self.num_envs = B = sum(b for b, _, _ in self.sizes)
+        stride = int(seed_stride) if seed_stride is not None else B
+        self.seed_stride, self.env_index_base = stride, int(env_index_base)
+        extra = dict(device=device, _library=_library) if _library is not None else dict(device=device)
+        probe = VectorGraphEnv(env_id, 1, self.sizes[0][1], self.sizes[0][2], _defer_create=True, **extra, **kwargs)
+        F, Fe, edge_env = probe.F, probe.Fe, env_id in ("SteinerTree-v0", "MulticastRouting-v0")
+        self._L = probe._L
+        dev = self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         Nn = sum(b * n for b, n, _ in self.sizes)
         Ne = sum(b * 2 * m for b, _, m in self.sizes)
-        dev = self.device
-        self.x = torch.zeros((Nn, F), dtype=torch.float32, device=dev)
-        self.edge_index = torch.zeros((2, Ne), dtype=torch.int64, device=dev)
-        self.edge_attr = torch.zeros((Ne, Fe), dtype=torch.float32, device=dev)
+        self.x, self.edge_index, self.edge_attr = z((Nn, F), torch.float32), z((2, Ne), torch.int64), z((Ne, Fe), torch.float32)
+        A_of = lambda n, m: 2 * m if edge_env else n
+        self.mask_flat = z((sum(b * A_of(n, m) for b, n, m in self.sizes),), torch.uint8)
+        self.g = {k: z((B,) + shape, dt) for k, (shape, dt) in _GLOBAL.items()}
+        self.g["reset_list"], self.g["reset_count"] = z((B,), torch.int32), z(((B + 255) // 256,), torch.int32)
+        self.g["work_list"], self.g["work_count"] = z((B,), torch.int32), z((4,), torch.int32)
         self.classes, self.slot_ptr = [], [0]
-        noff = eoff = slot = 0
+        noff = eoff = slot = moff = 0
         ptr = [0]
         for b, n, m in self.sizes:
-            E = 2 * m
-            views = dict(x=self.x[noff:noff + b * n], edge_index=self.edge_index[0, eoff:],
-                         edge_attr=self.edge_attr[eoff:eoff + b * E])
-            env = VectorGraphEnv(env_id, b, n, m, device=device, env_index_base=env_index_base + slot, seed_stride=stride,
-                                 _library=_library, _views=views, node_id_base=noff, edge_row_stride=Ne, **kwargs)
+            E, A = 2 * m, A_of(n, m)
+            views = dict(x=self.x[noff:noff + b * n], edge_index=self.edge_index[0, eoff:], edge_attr=self.edge_attr[eoff:eoff + b * E],
+                         mask=self.mask_flat[moff:moff + b * A].view(b, A))
+            views.update({k: self.g[k][slot:slot + b] for k in _GLOBAL})
+            views.update({k: self.g[k] for k in ("reset_list", "reset_count", "work_list", "work_count")})
+            env = VectorGraphEnv(env_id, b, n, m, env_index_base=self.env_index_base + slot, seed_stride=stride, autoreset=autoreset,
+                                 _views=views, node_id_base=noff, edge_row_stride=Ne, _defer_create=True, **extra, **kwargs)
             self.classes.append(env)
             ptr += [noff + (i + 1) * n for i in range(b)]
-            noff += b * n; eoff += b * E; slot += b
+            noff += b * n; eoff += b * E; slot += b; moff += b * A
             self.slot_ptr.append(slot)
+        nc = len(self.classes)
+        self._table = torch.zeros(int(self._L.ge_ragged_table_bytes(nc)), dtype=torch.uint8, device=dev)
+        self._slot_class, self._class_start = z((B,), torch.int32), z((nc + 1,), torch.int32)
+        cfgs = (_lib.GeConfig * nc)(*[c.cfg for c in self.classes])
+        bufs = (_lib.GeBuffers * nc)(*[c.bufs for c in self.classes])
+        h = C.c_void_p()
+        _lib.check(self._L, self._L.ge_create_ragged(cfgs, bufs, nc, self._table.data_ptr(), self._slot_class.data_ptr(),
+                                                     self._class_start.data_ptr(), C.byref(h)), "ge_create_ragged")
+        self._h = h
         self.ptr = torch.tensor(ptr, dtype=torch.int64, device=dev)
-        self.batch = torch.repeat_interleave(torch.arange(self.num_envs, device=dev), self.ptr[1:] - self.ptr[:-1])
-        self.mask_ptr = np.cumsum([0] + [c.num_envs * c.A for c in self.classes])
+        self.batch = torch.repeat_interleave(torch.arange(B, device=dev), self.ptr[1:] - self.ptr[:-1])
+        self._truncated = torch.zeros(B, dtype=torch.bool, device=dev)
+        self._actions = z((B,), torch.int64)
+        self._flat = None
+        self._was_reset = False
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else C.c_void_p(0)
 
     def graph(self):
         return GraphBatch(x=self.x, edge_index=self.edge_index, edge_attr=self.edge_attr, batch=self.batch, ptr=self.ptr,
                           num_graphs=self.num_envs)
 
-    def _split(self, t):
-        return [t[self.slot_ptr[i]:self.slot_ptr[i + 1]] for i in range(len(self.classes))]
-
-    def _cat(self, key):
-        return torch.cat([c.t[key] for c in self.classes])
-
     def _info(self, stepped):
         info = {"mask": [c.mask for c in self.classes],  # ragged: one [B_c, A_c] bool view per class
-                "mask_flat": torch.cat([c.mask.reshape(-1) for c in self.classes])}
+                "mask_flat": self.mask_flat.view(torch.bool)}
         if stepped:
-            info.update(solved=self._cat("solved"), solution_cost=self._cat("final_cost"),
-                        heuristic_solution=self._cat("final_heur"), invalid_action=self._cat("invalid").view(torch.bool))
+            g = self.g
+            info.update(solved=g["solved"], solution_cost=g["final_cost"], heuristic_solution=g["final_heur"],
+                        invalid_action=g["invalid"].view(torch.bool), episode_length=g["final_len"])
         return info
 
     def reset(self, seed=0):
-        for c, lo in zip(self.classes, self.slot_ptr):
-            c.reset(seed=int(seed) + 0)  # env_index_base already carries the class's first slot
+        s = (int(seed) + self.env_index_base + np.arange(self.num_envs, dtype=np.int64)) % (1 << 32)
+        self._seeds = torch.from_numpy(s.astype(np.uint32).view(np.int32)).to(self.device)
+        _lib.check(self._L, self._L.ge_reset(self._h, self._seeds.data_ptr(), self._stream()), "ge_reset")
+        self._was_reset = True
         return self.graph(), self._info(False)
 
     def step(self, actions):
-        actions = torch.as_tensor(actions).to(self.device, torch.int64)
-        for c, a in zip(self.classes, self._split(actions)):
-            c.step(a.contiguous())
-        return (self.graph(), self._cat("reward"), self._cat("terminated").view(torch.bool),
-                torch.zeros(self.num_envs, dtype=torch.bool, device=self.device), self._info(True))
+        actions = torch.as_tensor(actions).to(self.device, torch.int64).contiguous()
+        assert actions.shape == (self.num_envs,) and self._was_reset
+        self._act_keepalive = actions
+        _lib.check(self._L, self._L.ge_step(self._h, actions.data_ptr(), self._stream()), "ge_step")
+        g = self.g
+        return self.graph(), g["reward"], g["terminated"].view(torch.bool), self._truncated, self._info(True)
 
     def sample_random_actions(self, policy_seed=0):
-        return torch.cat([c.sample_random_actions(policy_seed).clone() for c in self.classes])
+        _lib.check(self._L, self._L.ge_sample_actions(self._h, int(policy_seed), self._actions.data_ptr(), self._stream()), "ge_sample_actions")
+        return self._actions
+
+    def random_rollout(self, n_steps, policy_seed=0):
+        _lib.check(self._L, self._L.ge_random_rollout(self._h, int(policy_seed), int(n_steps), self._actions.data_ptr(), self._stream()),
+                   "ge_random_rollout")
+
+    def flat_obs(self):
+        """utils.vectorize_graph of every slot, one [B_c, obs_len_c] tensor per class (views of one buffer)."""
+        lens = [c.num_envs * c.obs_len for c in self.classes]
+        if self._flat is None:
+            self._flat = torch.empty(sum(lens), dtype=torch.float32, device=self.device)
+        _lib.check(self._L, self._L.ge_vectorize(self._h, self._flat.data_ptr(), self._stream()), "ge_vectorize")
+        out, off = [], 0
+        for c, ln in zip(self.classes, lens):
+            out.append(self._flat[off:off + ln].view(c.num_envs, c.obs_len)); off += ln
+        return out
 
     def close(self):
-        for c in self.classes:
-            c.close()
+        if getattr(self, "_h", None):
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self._L.ge_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MixedVectorEnv:
@@ -101,6 +157,10 @@ class MixedVectorEnv:
 
     def sample_random_actions(self, policy_seed=0):
         return [m.sample_random_actions(policy_seed) for m in self.members]
+
+    def random_rollout(self, n_steps, policy_seed=0):
+        for m in self.members:
+            m.random_rollout(n_steps, policy_seed)
 
     def close(self):
         for m in self.members:

@@ -97,6 +97,20 @@ class _Space(SimpleNamespace):
     pass
 
 
+def _gymnasium():
+    """gymnasium when it is installed (it is not in the build image: everything gymnasium-specific is duck-typed otherwise)"""
+    try:
+        import gymnasium
+        return gymnasium
+    except ImportError:
+        return None
+
+
+_GYM = _gymnasium()
+# gymnasium.vector.VectorEnv when importable (SURVEY 8f-4), so that wrappers and trainers that check isinstance accept the engine
+_VectorBase = _GYM.vector.VectorEnv if _GYM is not None and hasattr(_GYM, "vector") and hasattr(_GYM.vector, "VectorEnv") else object
+
+
 class _Slabs(dict):
     """The engine's device slabs by name (what ge_buffers points at).  The scalar state of a slot is packed into
     ``slot_rec`` [B, 2] = {cost as float64 bits, head | status << 16 | aux << 24 | tstep << 32} (include/graphenvs.h
@@ -119,12 +133,13 @@ class _Slabs(dict):
         raise KeyError(key)
 
 
-class VectorGraphEnv:
-    """B independent envs of one id on one GPU.  One instance per process/GPU; no global state."""
+class VectorGraphEnv(_VectorBase):
+    """B independent envs of one id on one GPU.  One instance per process/GPU; no global state.  A subclass of
+    gymnasium.vector.VectorEnv when gymnasium is installed (num_envs, single_*_space, *_space, metadata['autoreset_mode'])."""
 
     def __init__(self, env_id, num_envs, n_nodes, n_edges=-1, device="cuda", autoreset=True, obs_mode="pyg",
                  env_index_base=0, seed_stride=None, strict=False, _library=None, _views=None, node_id_base=0,
-                 edge_row_stride=0, record_actions=False, copy_outputs=False, **kwargs):
+                 edge_row_stride=0, record_actions=False, copy_outputs=False, _defer_create=False, **kwargs):
         self.env_id = env_id
         self.kwargs = normalize_kwargs(env_id, n_nodes, n_edges, **kwargs)
         self.num_envs = int(num_envs)
@@ -213,13 +228,16 @@ class VectorGraphEnv:
         t["actions_out"] = z((B,), torch.int64) if record_actions else None
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
+                if t[k] is None:
+                    continue
                 assert v.dtype == t[k].dtype and v.numel() >= (t[k].numel() if k != "edge_index" else 0), k
                 t[k] = v
         self.node_id_base = int(node_id_base)
         self.t = t = _Slabs(t)
-        bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in dict.items(t)})
+        self.bufs = _lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in dict.items(t)})
         h = C.c_void_p()
-        _lib.check(self._L, self._L.ge_create(C.byref(self.cfg), C.byref(bufs), C.byref(h)), "ge_create")
+        if not _defer_create:  # (a size class of a multi-class engine is created by RaggedVectorEnv, all classes at once)
+            _lib.check(self._L, self._L.ge_create(C.byref(self.cfg), C.byref(self.bufs), C.byref(h)), "ge_create")
         self._h = h
         # static parts of the PyG view
         self._batch = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(n)
@@ -230,6 +248,13 @@ class VectorGraphEnv:
         self._was_reset = False
         self.single_action_space = _Space(n=(self.m if edge_env else n), mask_size=A)  # steiner_tree.py:43, multicast_routing.py:67
         self.single_observation_space = _Space(shape=(self.obs_len,), dtype=np.float32)
+        if _GYM is not None and hasattr(_GYM, "spaces"):  # the reference's spaces (shortest_path.py:40-42), and their batched forms
+            sp = _GYM.spaces
+            self.single_action_space = sp.Discrete(self.m if edge_env else n)
+            self.single_observation_space = sp.Box(low=-np.inf, high=np.inf, shape=(self.obs_len,), dtype=np.float32)
+            self.action_space = sp.MultiDiscrete([self.m if edge_env else n] * B) if hasattr(sp, "MultiDiscrete") else None
+            self.observation_space = sp.Box(low=-np.inf, high=np.inf, shape=(B, self.obs_len), dtype=np.float32)
+            self.metadata = {"autoreset_mode": {0: "disabled", 1: "same_step", 2: "next_step"}[self.autoreset_mode]}
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):

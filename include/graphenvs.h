@@ -172,6 +172,25 @@ int ge_get_layout(const ge_config *cfg, ge_layout *out);
 int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine **out);
 int ge_destroy(ge_engine *e);
 
+/* Multi-class ("ragged") engine -- BASELINE config 5: env instances of ONE id but different (n_nodes, n_edges) stepped by one launch
+ * sequence.  Every reference instance has a fixed geometry (shortest_path.py:23-45, densest_subgraph.py:25-50,
+ * max_independent_set.py:25-38), so a ragged batch is a list of size classes; class c is described exactly like a uniform engine
+ * (cfgs[c], bufs[c]) and owns slots [start_c, start_c + num_envs_c) of the global slot order, start_c = sum of the earlier classes:
+ *  - cfgs[c].env_index_base = cfgs[0].env_index_base + start_c; env_type, autoreset, seed_stride equal in all classes;
+ *  - seed, episode, mt_state are ENGINE-wide arrays in slot order (bufs[c].seed = bufs[0].seed + start_c, ...); reset_list,
+ *    reset_count, work_list, work_count (and actions_out) are taken from bufs[0] and sized for all slots; callers normally make
+ *    every per-slot array engine-wide the same way and let the classes share the observation slabs through node_id_base /
+ *    edge_row_stride (variable-size CSR packing: the policy sees ONE PyG Batch);
+ *  - class_table (ge_ragged_table_bytes(n_classes) bytes), slot_class [all slots] int32 and class_start [n_classes + 1] int32 are
+ *    device buffers the engine fills once, here (a synchronous copy).
+ * ge_reset / ge_step / ge_sample_actions / ge_random_rollout / ge_vectorize then take arrays over ALL slots (ge_vectorize: the classes'
+ * flat vectors one class after the other).  Every kernel maps a slot to its class and runs the class's code path; classes with
+ * n_nodes <= 64 use the fast feature kernel, the others the generic one, inside the same launch sequence.  Built for ShortestPath,
+ * DensestSubgraph and MaxIndependentSet; ge_inject_state is not available. */
+int64_t ge_ragged_table_bytes(int32_t n_classes);
+int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, int32_t n_classes, void *class_table,
+                     int32_t *slot_class, int32_t *class_start, ge_engine **out);
+
 /* env.reset(seed=s) for every slot (shortest_path.py:47-98 and the five siblings):
  * seeds [B] uint32 on device = first-episode seed per slot (read on `stream` only); sets episode = 0.
  * Runs graph sampling, weights (a8), terminals (a9), structural features (a6),

@@ -35,6 +35,10 @@ CASES = {
     "lp_n10_m20_p1": ("LongestPath-v0", dict(n_nodes=10, n_edges=20, parenting=1, is_eval_env=True), list(range(8))),
     "lp_n10_m20_p2": ("LongestPath-v0", dict(n_nodes=10, n_edges=20, parenting=2, is_eval_env=True), list(range(8))),
     "lp_n64_m192_p2": ("LongestPath-v0", dict(n_nodes=64, n_edges=192, parenting=2), list(range(4))),
+    # parenting 3 (longest_path.py:141-143) re-opens every residual node once <= n // 3 are left; the step asserts then reject a
+    # non-neighbour (:153).  The fixture records where the reference raised (policy_raised / policy_raise_action).
+    "lp_n12_m24_p3": ("LongestPath-v0", dict(n_nodes=12, n_edges=24, parenting=3, is_eval_env=True), list(range(12))),
+    "lp_n30_m60_p3": ("LongestPath-v0", dict(n_nodes=30, n_edges=60, parenting=3), list(range(6))),
     "st_n10_m20_d3_eval": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=3, is_eval_env=True), list(range(8))),
     "st_n10_m20_d1_eval": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=1, is_eval_env=True), list(range(6))),
     "st_n10_m20_d9_eval": ("SteinerTree-v0", dict(n_nodes=10, n_edges=20, n_dests=9, is_eval_env=True), list(range(6))),
@@ -136,12 +140,16 @@ def roll(gym, env_id, kwargs, seed, policy, max_steps=4000):
     rng = np.random.default_rng(1000 + seed)
     acts, rews, dones, masks, shas = [], [], [], [], []
     mask = info["mask"]
-    final = dict(solved=-1, solution_cost=np.nan, heuristic_solution=np.nan)
+    final = dict(solved=-1, solution_cost=np.nan, heuristic_solution=np.nan, raised=0, raise_action=-1)
     for _ in range(max_steps):
         a = pick(policy, mask, rng)
         if a < 0:
             break
-        obs, r, d, trunc, info = env.step(a)
+        try:
+            obs, r, d, trunc, info = env.step(a)
+        except AssertionError:  # the reference's own asserts on an action its mask allowed (LongestPath parenting 3)
+            final["raised"], final["raise_action"] = 1, a
+            break
         assert trunc is False
         acts.append(a); rews.append(float(r)); dones.append(bool(d)); shas.append(sha64(obs))
         if "mask" in info:
@@ -190,6 +198,9 @@ def build_case(gym, name):
         out[P + "solved"] = np.array([r["solved"] for r in recs], dtype=np.int8)
         out[P + "solution_cost"] = np.array([r["solution_cost"] for r in recs], dtype=np.float64)
         out[P + "heuristic_solution"] = np.array([r["heuristic_solution"] for r in recs], dtype=np.float64)
+        if any(r["raised"] for r in recs):
+            out[P + "raised"] = np.array([r["raised"] for r in recs], dtype=np.int8)
+            out[P + "raise_action"] = np.array([r["raise_action"] for r in recs], dtype=np.int32)
         out[P + "reset2_obs_sha"] = np.array([r["reset2_obs_sha"] for r in recs], dtype=np.uint64)
         out[P + "reset2_mask"] = np.stack([r["reset2_mask"] for r in recs])
         if policy == POLICIES[0]:

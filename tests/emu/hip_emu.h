@@ -36,6 +36,8 @@ static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#define hipMemcpyHostToDevice 1
+static inline hipError_t hipMemcpy(void *dst, const void *src, size_t n, int) { memcpy(dst, src, n); return hipSuccess; }
 #define hipStreamNonBlocking 1
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

@@ -92,6 +92,14 @@ def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True
                 assert np.array_equal(np.asarray(info["mask"]), want_mask), tag + ": mask"
                 if feature_ulps == 0:
                     assert sha64(np.asarray(obs)) == case[pol + "_obs_sha"][si, t], tag + ": obs hash"
+            if pol + "_raised" in case and int(case[pol + "_raised"][si]):
+                # the reference raised AssertionError on an action its own mask allowed (LongestPath parenting 3, longest_path.py:141-153)
+                bad = int(case[pol + "_raise_action"][si])
+                try:
+                    env.step(bad)
+                    raise RuntimeError(f"{meta['case']} seed {seed} {pol}: action {bad} should be rejected like the reference's assert")
+                except AssertionError:
+                    stats["reference_asserts_reproduced"] = stats.get("reference_asserts_reproduced", 0) + 1
             if T:
                 obs_equal(np.asarray(obs), case[pol + "_final_obs"][si], f"{meta['case']} seed {seed} {pol}: final obs")
                 if bool(case[pol + "_dones"][si, T - 1]):

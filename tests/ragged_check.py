@@ -4,11 +4,25 @@ import numpy as np
 import torch
 
 
-def check_ragged_mixed(ge, oracle, device, library=None, steps=25):
+def config5_specs(n_sizes=66, slots_per_class=2, seed=5):
+    """BASELINE config 5: {ShortestPath, MaxIndependentSet (= the README's MinVertexCover), DensestSubgraph}, n ~ U{32..512}, m = 3n:
+    n_sizes distinct sizes per env id, the extremes and the 64 / 65 boundary of the feature fast path always among them"""
+    rng = np.random.default_rng(seed)
+    specs = []
+    for eid, extra in (("ShortestPath-v0", {}), ("MaxIndependentSet-v0", {}), ("DensestSubgraph-v0", dict(parenting=1))):
+        ns = {32, 64, 65, 512}
+        while len(ns) < n_sizes:
+            ns.add(int(rng.integers(32, 513)))
+        order = [int(v) for v in rng.permutation(sorted(ns))]  # classes in no particular order: small and large graphs interleaved
+        specs.append((eid, [(slots_per_class, n, 3 * n) for n in order], extra))
+    return specs
+
+
+def check_ragged_mixed(ge, oracle, device, library=None, steps=25, specs=None):
     kw = dict(device=device, _library=library) if library is not None else dict(device=device)
-    specs = [("ShortestPath-v0", [(3, 32, 96), (2, 45, 135), (2, 64, 192), (1, 130, 390)], {}),
-             ("MaxIndependentSet-v0", [(2, 32, 96), (2, 70, 210)], {}),
-             ("DensestSubgraph-v0", [(2, 33, 96), (2, 90, 270)], dict(parenting=1))]
+    specs = specs or [("ShortestPath-v0", [(3, 32, 96), (2, 45, 135), (2, 64, 192), (1, 130, 390)], {}),
+                      ("MaxIndependentSet-v0", [(2, 32, 96), (2, 70, 210)], {}),
+                      ("DensestSubgraph-v0", [(2, 33, 96), (2, 90, 270)], dict(parenting=1))]
     members = [ge.RaggedVectorEnv(eid, sizes, **kw, **extra) for eid, sizes, extra in specs]
     mixed = ge.MixedVectorEnv(members)
     graphs, infos = mixed.reset(seed=11)

@@ -132,3 +132,72 @@ def test_hopeless_rejection_sampling_is_refused_without_a_gpu():
     assert L.ge_get_layout(C.byref(cfg), C.byref(lay)) == -2 and b"probability" in L.ge_last_error()
     cfg = _lib.GeConfig(0, 4, 64, 70, 1, -1, 0, 0, 0, 1, -1.0, 0, 4, 0, 0, 0.0, 0.0, 0.0)  # ~1 400 attempts on average: fine
     assert L.ge_get_layout(C.byref(cfg), C.byref(lay)) == 0
+
+
+_STANDINS = {
+    "gymnasium/__init__.py": """
+from . import spaces, vector
+from .envs.registration import register, registry
+def make(id, **kw):
+    return registry[id](**kw)
+""",
+    "gymnasium/spaces.py": """
+class Discrete:
+    def __init__(self, n): self.n = n
+class MultiDiscrete:
+    def __init__(self, nvec): self.nvec = list(nvec)
+class Box:
+    def __init__(self, low, high, shape, dtype): self.shape, self.dtype = tuple(shape), dtype
+""",
+    "gymnasium/vector/__init__.py": """
+class VectorEnv:
+    metadata = {}
+""",
+    "gymnasium/envs/__init__.py": "",
+    "gymnasium/envs/registration.py": """
+registry = {}
+def register(id, entry_point, **kw):
+    registry[id] = entry_point
+""",
+    "torch_geometric/__init__.py": "",
+    "torch_geometric/data.py": """
+class Data:
+    def __init__(self, **kw): self.__dict__.update(kw)
+class Batch(Data):
+    pass
+""",
+}
+
+
+def test_gymnasium_and_pyg_integration_with_stand_in_packages(tmp_path):
+    """SURVEY 8f-4 / VERDICT r1 item 7: gymnasium and torch_geometric are not in the image, so the branches that use them run here
+    against minimal stand-in packages (what refshim.py does for the reference): VectorGraphEnv subclasses gymnasium.vector.VectorEnv,
+    the nine ids register and gymnasium.make() builds the facade, GraphBatch.to_pyg() yields a torch_geometric Batch."""
+    import subprocess, sys, textwrap
+    for rel, body in _STANDINS.items():
+        f = tmp_path / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(textwrap.dedent(body))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{str(tmp_path)!r}, {ROOT!r}, {os.path.join(ROOT, 'tests', 'emu')!r}]
+        import gymnasium, torch_geometric.data
+        import graphenvs_amd as ge, build_emu
+        emu = build_emu.load()
+        assert issubclass(ge.VectorGraphEnv, gymnasium.vector.VectorEnv)
+        ge.register_with_gymnasium()
+        assert sorted(gymnasium.registry) == sorted(ge.ENV_IDS) and len(ge.ENV_IDS) == 9
+        env = gymnasium.make("ShortestPath-v0", n_nodes=8, n_edges=14, device="cpu", _library=emu)
+        obs, info = env.reset(seed=3)
+        assert obs.shape == (7 * 8 + 6 * 14,) and info["mask"].dtype == bool
+        v = ge.VectorGraphEnv("SteinerTree-v0", 3, 8, 14, n_dests=2, device="cpu", _library=emu)
+        assert isinstance(v, gymnasium.vector.VectorEnv) and v.num_envs == 3
+        assert v.single_action_space.n == 14 and v.observation_space.shape == (3, v.obs_len) and v.metadata["autoreset_mode"] == "same_step"
+        g, info = v.reset(seed=1)
+        b = g.to_pyg()
+        assert isinstance(b, torch_geometric.data.Batch) and b.x.shape == (24, 7) and b.edge_index.shape == (2, 84) and b._num_graphs == 3
+        assert int(b.ptr[-1]) == 24 and int(b.batch[-1]) == 2
+        print("ok")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

@@ -542,3 +542,13 @@ def test_state_dict_moves_between_engines():
 def test_return_graph_obs_and_copy_outputs():
     import host_checks as hc
     hc.check_graph_obs(_ge(), "cuda", None)
+
+
+def test_config5_ragged_batch_one_engine_per_env_id():
+    """BASELINE config 5 for real: three env ids, 66 distinct sizes each from U{32..512} (n = 512 inside the slab), every slot
+    replayed on the oracle; ONE multi-class engine -- one launch sequence -- per env id."""
+    import oracle
+    from ragged_check import check_ragged_mixed, config5_specs
+    specs = config5_specs()
+    assert all(len({n for _, n, _ in sizes}) >= 64 and max(n for _, n, _ in sizes) == 512 for _, sizes, _ in specs)
+    check_ragged_mixed(_ge(), oracle, "cuda", steps=70, specs=specs)

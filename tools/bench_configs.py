@@ -16,7 +16,32 @@ CONFIGS = {
     "dc": ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), 65536, 100),
     "ppd": ("PerishableProductDelivery-v0", dict(n_nodes=64, n_edges=192, parenting=1), 16384, 300),
 }
+def bench_c5(slots_per_id=16384, n_sizes=481, K=100):
+    """BASELINE config 5: mixed {ShortestPath, MaxIndependentSet, DensestSubgraph}, n ~ U{32..512} (every size), m = 3n; one
+    multi-class engine (one launch sequence) per env id"""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    members = []
+    for eid, extra in (("ShortestPath-v0", {}), ("MaxIndependentSet-v0", {}), ("DensestSubgraph-v0", dict(parenting=1))):
+        ns = rng.integers(32, 513, slots_per_id)
+        sizes = [(int((ns == n).sum()), int(n), 3 * int(n)) for n in np.unique(ns)]
+        members.append(ge.RaggedVectorEnv(eid, sizes, **extra))
+    mixed = ge.MixedVectorEnv(members)
+    t0 = time.perf_counter(); mixed.reset(seed=0); torch.cuda.synchronize(); t_reset = time.perf_counter() - t0
+    mixed.random_rollout(10, policy_seed=1); torch.cuda.synchronize()
+    ep0 = sum(int(m.g["episode"].sum()) for m in members)
+    t0 = time.perf_counter(); mixed.random_rollout(K, policy_seed=1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    B = mixed.num_envs
+    print(json.dumps(dict(config="c5", envs=B, size_classes=[len(m.classes) for m in members], steps=K, env_steps_per_s=B * K / dt,
+                          ms_per_vector_step=dt * 1e3 / K, episodes=sum(int(m.g["episode"].sum()) for m in members) - ep0,
+                          full_reset_ms=t_reset * 1e3, launch_sequences_per_step=len(members))), flush=True)
+    mixed.close()
+
+
 for name in (sys.argv[1:] or ["c3", "c4"]):
+    if name == "c5":
+        bench_c5()
+        continue
     env_id, kw, B, K = CONFIGS[name]
     env = ge.make_vec(env_id, B, **kw)
     t0 = time.perf_counter(); env.reset(seed=0); torch.cuda.synchronize(); t_reset = time.perf_counter() - t0
