@@ -59,7 +59,8 @@ def step_kernel_us(env, reps=9, burst=5, seed0=2000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 200; c3: 256 = two whole TSP episodes, every slot resets exactly "
+                    "twice whatever the phase of the window; c4: 400)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="env slots per GPU (default: the config's)")
@@ -90,6 +91,8 @@ def main():
     import graphenvs_amd as ge
 
     cfg = CONFIGS[args.config]
+    if args.steps <= 0:
+        args.steps = {"c2": 200, "c3": 256, "c4": 400}[args.config]
     B = args.envs or cfg["envs"]
     dev = f"cuda:{local_rank}"
     env = ge.make_vec(cfg["env_id"], B, device=dev, env_index_base=rank * B, seed_stride=world * B, **cfg["kw"])
@@ -115,10 +118,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     episodes = int(env.t["episode"].sum()) - ep0
-    assert int(env.t["tstep"].sum()) == B * (args.steps + args.warmup + settle)
+    assert int(env.t["tstep"].sum()) == B * (args.steps + args.warmup + settle) % (1 << 32) or B * (args.steps + args.warmup + settle) >= (1 << 32)
     value = world * B * args.steps / dt
     # reference window: the reset rate of the steady state, to judge the timed window against
-    REF = 200
+    REF = 200 if args.config == "c2" else args.steps
     env.random_rollout(REF, policy_seed=1)
     torch.cuda.synchronize()
     ref_rate = (int(env.t["episode"].sum()) - ep0 - episodes) / REF

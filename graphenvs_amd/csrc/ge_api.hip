@@ -272,16 +272,16 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
       rc = fail(GE_E_BADARG, "classes follow one another in slot order: env_index_base, seed, episode and mt_state of class c start at its first global slot");
     if (rc != GE_OK) { delete e; return rc; }
     C.buf = bufs[c];
-    C.feat_parts = 1;
     start[c + 1] = start[c] + cfgs[c].num_envs;
     for (int i = start[c]; i < start[c + 1]; i++) cls_of[(size_t)i] = c;
-    if (C.n > 64 && C.ldsf.waves < wmin) wmin = C.ldsf.waves;
+    if (C.n > 64) { GeParams T = C; ge_make_ldsf(T, (int)total, 0, 160 * 1024 - 2048); if (T.ldsf.waves < wmin) wmin = T.ldsf.waves; }
     if (C.n > e->classes[widest].n) widest = c;
   }
   for (GeParams &C : e->classes) ge_make_ldsf(C, (int)total, wmin);  // one launch geometry of the generic feature kernel for every class
   // engine-wide block: the widest class's geometry (LDS stage of the step kernel), all slots, the global arrays of class 0
   e->P = e->classes[widest];
   e->P.B = (int32_t)total;
+  for (const GeParams &C : e->classes) if (C.feat_parts > e->P.feat_parts) e->P.feat_parts = C.feat_parts;
   e->P.buf = bufs[0];
   e->P.env_index_base = cfgs[0].env_index_base;
   e->cfg = cfgs[0]; e->cfg.num_envs = (int32_t)total;
@@ -318,6 +318,16 @@ static int launch_seed(ge_engine *e, const uint32_t *seeds, int jlo, void *strea
   return check_launch("seed kernel");
 }
 
+static int launch_combine(ge_engine *e, int mode, void *stream) {
+  const bool rg = e->n_classes > 0;
+  size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
+  int64_t items = (int64_t)(mode == GE_RESET_ALL ? e->P.B : 4096) * e->P.n;
+  int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
+  if (rg) GE_LAUNCH(ge_k_feat_combine<true>, grid, 256, lds, stream, e->P, e->R, mode);
+  else GE_LAUNCH(ge_k_feat_combine<false>, grid, 256, lds, stream, e->P, e->R, mode);
+  return check_launch("feature combine kernel");
+}
+
 static int launch_features(ge_engine *e, int mode, void *stream) {
   int rc = GE_OK;
   const bool rg = e->n_classes > 0;
@@ -328,10 +338,16 @@ static int launch_features(ge_engine *e, int mode, void *stream) {
     else GE_LAUNCH(ge_k_features64<false>, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, e->R, mode, e->feat64_pre_off);
     rc = check_launch("feature kernel (n <= 64)");
     if (rc != GE_OK) return rc;
-    // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64
-    int g2 = e->gen_grid < 64 && !rg ? e->gen_grid : (rg ? e->gen_grid : 64);
-    if (rg) GE_LAUNCH(ge_k_features<true>, g2, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
-    else GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
+    // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64, feat_parts workgroups each
+    if (rg) {
+      int64_t want = (int64_t)e->gen_grid * e->P.feat_parts * (mode == GE_RESET_QUEUE ? 1 : 4);
+      if (want > 65535 * 16) want = 65535 * 16;
+      GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
+      rc = check_launch("feature kernel (list)");
+      return (rc == GE_OK && e->P.feat_parts > 1) ? launch_combine(e, GE_FEAT_LIST, stream) : rc;
+    }
+    int g2 = e->gen_grid < 64 ? e->gen_grid : 64;
+    GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
     return check_launch("feature kernel (fallback list)");
   }
   {
@@ -342,14 +358,8 @@ static int launch_features(ge_engine *e, int mode, void *stream) {
     else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);
   }
   rc = check_launch("feature kernel");
-  if (rc != GE_OK || e->P.feat_parts == 1 || rg) return rc;
-  {
-    size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
-    int64_t items = (int64_t)(mode == GE_RESET_QUEUE ? 4096 : e->P.B) * e->P.n;
-    int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
-    GE_LAUNCH(ge_k_feat_combine, grid, 256, lds, stream, e->P, mode);
-  }
-  return check_launch("feature combine kernel");
+  if (rc != GE_OK || e->P.feat_parts == 1) return rc;
+  return launch_combine(e, mode, stream);
 }
 
 // mode GE_RESET_ALL / GE_RESET_INJECT: every slot; GE_RESET_QUEUE: the slots the last step launch queued.  Everything on the

@@ -413,38 +413,47 @@ GE_KERNEL ge_k_features(GeParams P, GeRagged R, int mode, int pre_off) {
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
-  const int nparts = (mode == GE_FEAT_LIST) ? 1 : P.feat_parts;
+  // workgroups per item: the uniform engine's fallback list is rare and small (one workgroup each); the multi-class engine sends
+  // every slot of a class with n > 64 through the list, feat_parts workgroups each (P.feat_parts = the largest class's)
+  const int nparts = (mode == GE_FEAT_LIST && !RAGGED) ? 1 : P.feat_parts;
   for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
-    const int item = q / nparts;
+    const int item = q / nparts, part = q % nparts;
     const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
-    if (mode == GE_RESET_QUEUE && q % nparts == 0 && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
+    if (mode == GE_RESET_QUEUE && part == 0 && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
     if constexpr (RAGGED) {
       const int cls = ge_slot_class(R, env);
-      ge_features_generic_env(R.classes[cls], env - R.class_start[cls], 0, 1);
+      const GeParams &C = R.classes[cls];
+      if (part < C.feat_parts) ge_features_generic_env(C, env - R.class_start[cls], part, C.feat_parts);  // uniform per workgroup
     } else {
-      ge_features_generic_env(P, env, q % nparts, nparts);
+      ge_features_generic_env(P, env, part, nparts);
     }
   }
 }
 
-// betweenness of multi-part slots: parts added in part order, then the 1/((n-1)(n-2)) rescale and the float32 cast
-GE_KERNEL ge_k_feat_combine(GeParams P, int mode) {
+// betweenness of multi-part slots: parts added in part order, then the 1/((n-1)(n-2)) rescale and the float32 cast.  Multi-class
+// engine: items are (slot, node) over the widest class's n; a thread looks up its slot's class and skips what does not exist there.
+template <bool RAGGED>
+GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, int mode) {
   int *pre = (int *)ge_dyn_smem();
-  int count = P.B;
+  int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
   if (mode == GE_RESET_QUEUE) {
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
-  const int n = P.n, nparts = P.feat_parts;
-  const double scale = n > 2 ? 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)) : 1.0;
-  for (int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid(); g < (int64_t)count * n; g += (int64_t)ge_gdim() * ge_bdim()) {
-    const int item = (int)(g / n), v = (int)(g % n);
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : item;
+  const int nmax = P.n;
+  for (int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid(); g < (int64_t)count * nmax; g += (int64_t)ge_gdim() * ge_bdim()) {
+    const int item = (int)(g / nmax), v = (int)(g % nmax);
+    int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
+    int cls = 0;
+    if constexpr (RAGGED) { cls = R.slot_class[env]; env -= R.class_start[cls]; }
+    const GeParams &C = RAGGED ? R.classes[cls] : P;
+    const int n = C.n, nparts = C.feat_parts;
+    if (v >= n || nparts == 1) continue;
     double acc = 0.0;
-    for (int p = 0; p < nparts; p++) acc += P.buf.feat_scratch[((int64_t)env * nparts + p) * n + v];
-    if (n > 2) acc *= scale;
-    P.buf.x[((int64_t)env * n + v) * P.F + P.nflag + 1] = (float)acc;
+    for (int p = 0; p < nparts; p++) acc += C.buf.feat_scratch[((int64_t)env * nparts + p) * n + v];
+    if (n > 2) acc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
+    C.buf.x[((int64_t)env * n + v) * C.F + C.nflag + 1] = (float)acc;
   }
 }
 

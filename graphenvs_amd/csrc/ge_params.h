@@ -117,7 +117,9 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
 }
 
 // force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry for every class)
-static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0) {
+// budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU; the multi-class engine runs
+// its large classes one workgroup per CU)
+static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, int budget = 160 * 1024 / 2) {
   GeLdsF &L = P.ldsf;
   int o = 0;
   auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
@@ -129,7 +131,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0) {
   // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
   const int shared = o + 1024 + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
   L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
-  int waves = (160 * 1024 / 2 - shared) / (per_wave > 0 ? per_wave : 1);  // aim at two workgroups per CU
+  int waves = (budget - shared) / (per_wave > 0 ? per_wave : 1);
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
   if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here

@@ -137,6 +137,9 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
     }
     if (!progressed && !released) die("deadlock: a barrier or wave collective was not reached by every live lane (divergent rendezvous)");
   }
+  // LDS overrun detector: the 64 bytes behind the requested dynamic LDS were poisoned above and must still be
+  for (size_t k = smem_bytes; k < smem_bytes + 64; k++)
+    if (b.smem[k] != 0xCD) { fprintf(stderr, "[hip_emu] block %d wrote past its %zu bytes of dynamic LDS (offset %zu)\n", bid, smem_bytes, k); abort(); }
 }
 
 template <class Fn>
