@@ -118,7 +118,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     episodes = int(env.t["episode"].sum()) - ep0
-    assert int(env.t["tstep"].sum()) == B * (args.steps + args.warmup + settle) % (1 << 32) or B * (args.steps + args.warmup + settle) >= (1 << 32)
+    assert int(env.t["tstep"].sum()) == B * (args.steps + args.warmup + settle)
     value = world * B * args.steps / dt
     # reference window: the reset rate of the steady state, to judge the timed window against
     REF = 200 if args.config == "c2" else args.steps

@@ -250,6 +250,13 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   const int q = tid & (GE_F64_QL - 1);
   const ge_slice_t slice_mask = (GE_F64_SLICE >= 32) ? (ge_slice_t)~(ge_slice_t)0 : (ge_slice_t)((1u << (GE_F64_SLICE & 31)) - 1u);
   const bool walker = !node_wave && s < n;
+  // push targets of this lane: node (SLICE q + b), b = bit inside the slice.  The sigma counters are half-words, two to a dword;
+  // a row is GE_F64_SS (even) half-words, so the dword of (node, s) is row * SS/2 + (s >> 1) and the half inside it depends on s
+  // alone: one multiply-add per push instead of rebuilding the index
+  static_assert(GE_F64_SS % 2 == 0, "sigma rows must be whole dwords");
+  uint32_t *const sig_mine = (uint32_t *)c.sig + (GE_F64_SLICE * q) * (GE_F64_SS / 2) + (s >> 1);
+  const int sig_sh = 16 * (s & 1);
+  double *const del_mine = c.del + (GE_F64_SLICE * q) * GE_F64_SD + s;
   bool ovf = false;
   int D = 0, reach = 1; int64_t tot = 0;
   GE_STAMP_T0(24);
@@ -276,14 +283,13 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
       nxt |= cand | cand2;
       // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
       ge_slice_t mine = (ge_slice_t)(cand >> ((GE_F64_SLICE * q) & 63)) & slice_mask, mine2 = (ge_slice_t)(cand2 >> ((GE_F64_SLICE * q) & 63)) & slice_mask;
+      const uint32_t add1 = su << sig_sh, add2 = su2 << sig_sh;
       while (mine | mine2) {
         if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
-          const int idx = (GE_F64_SLICE * q + GE_SLICE_CTZ(mine)) * GE_F64_SS + s; mine &= mine - 1;
-          ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su << (16 * (idx & 1)));
+          ge_lds_add_u32(sig_mine + GE_SLICE_CTZ(mine) * (GE_F64_SS / 2), add1); mine &= mine - 1;
         }
         if (mine2) {
-          const int idx = (GE_F64_SLICE * q + GE_SLICE_CTZ(mine2)) * GE_F64_SS + s; mine2 &= mine2 - 1;
-          ge_lds_add_u32((uint32_t *)c.sig + (idx >> 1), su2 << (16 * (idx & 1)));
+          ge_lds_add_u32(sig_mine + GE_SLICE_CTZ(mine2) * (GE_F64_SS / 2), add2); mine2 &= mine2 - 1;
         }
       }
     }
@@ -360,8 +366,8 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
       // lane, w before w2, iteration after iteration: the float64 sum order is fixed
       ge_slice_t mine = (ge_slice_t)(pb >> ((GE_F64_SLICE * q) & 63)) & slice_mask, mine2 = (ge_slice_t)(pb2 >> ((GE_F64_SLICE * q) & 63)) & slice_mask;
       while (mine | mine2) {
-        if (mine) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + GE_SLICE_CTZ(mine)) * GE_F64_SD + s], coeff); mine &= mine - 1; }  // ds_add_f64
-        if (mine2) { ge_lds_add_f64(&c.del[(GE_F64_SLICE * q + GE_SLICE_CTZ(mine2)) * GE_F64_SD + s], coeff2); mine2 &= mine2 - 1; }
+        if (mine) { ge_lds_add_f64(del_mine + GE_SLICE_CTZ(mine) * GE_F64_SD, coeff); mine &= mine - 1; }  // ds_add_f64
+        if (mine2) { ge_lds_add_f64(del_mine + GE_SLICE_CTZ(mine2) * GE_F64_SD, coeff2); mine2 &= mine2 - 1; }
       }
     }
   }
