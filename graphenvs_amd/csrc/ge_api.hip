@@ -114,6 +114,7 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   P.spatial = (t == GE_TSP && cfg->spatial) ? 1 : 0;
   P.is_eval = cfg->is_eval_env ? 1 : 0; P.autoreset = cfg->autoreset == 2 ? 2 : (cfg->autoreset ? 1 : 0);
   P.complete = (m >= max_edges) ? 1 : 0;
+  P.div_m = ((1ull << 40) / (uint64_t)(ng > 1 ? ng - 1 : 1)) + 1ull;
   P.n_choices = (cfg->n_choices < 0) ? floor((double)n / exp(1.0)) : cfg->n_choices;  // densest_subgraph.py:38-39
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
   P.node_id_base = cfg->node_id_base;
@@ -418,6 +419,20 @@ static size_t step_lds(const ge_engine *e) { return (size_t)GE_STEP_BLOCK * e->P
 
 extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *actions, void *stream);
 
+// parenting >= 2 of LongestPath / TSP: the instantiation of the step kernel that carries the residual-graph walks
+static bool prunes(const ge_engine *e) { return (e->P.env_type == GE_LONGEST_PATH || e->P.env_type == GE_TSP) && e->P.parenting >= 2; }
+#define GE_LAUNCH_STEP(SAMPLE, actions_arg, seed_arg)                                                                                   \
+  do {                                                                                                                                  \
+    if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, true, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
+    else if (path64(e)) GE_LAUNCH(ge_k_step_path64<SAMPLE>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
+    else if (prunes(e) && e->P.env_type == GE_TSP) GE_LAUNCH((ge_k_step<GE_TSP, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
+    else if (prunes(e)) GE_LAUNCH((ge_k_step<GE_LONGEST_PATH, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
+    else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, false, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
+  } while (0)
+
+static bool path64(const ge_engine *e);
+static size_t step_lds(const ge_engine *e);
+
 static bool path64(const ge_engine *e) {
   return e->n_classes == 0 && (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1 && e->P.parenting < 2;
 }
@@ -440,9 +455,7 @@ extern "C" int ge_step_only(ge_engine *e, const int64_t *actions, void *stream) 
     if (rc != GE_OK) return rc;
   }
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions, (uint64_t)0));
-  else if (path64(e)) GE_LAUNCH(ge_k_step_path64<false>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions, (uint64_t)0);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, false, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions, (uint64_t)0));
+  GE_LAUNCH_STEP(false, actions, (uint64_t)0);
   return check_launch("step kernel");
 }
 
@@ -457,9 +470,7 @@ static int sample_and_step(ge_engine *e, uint64_t policy_seed, int64_t *scratch,
     return rc == GE_OK ? ge_step_only(e, scratch, stream) : rc;
   }
   int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, (const int64_t *)nullptr, policy_seed));
-  else if (path64(e)) GE_LAUNCH(ge_k_step_path64<true>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, (const int64_t *)nullptr, policy_seed);
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, true, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, (const int64_t *)nullptr, policy_seed));
+  GE_LAUNCH_STEP(true, (const int64_t *)nullptr, policy_seed);
   return check_launch("fused sample+step kernel");
 }
 

@@ -48,8 +48,8 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
   for (int idx = tid; idx < E; idx += nthreads) c.colw[idx] = G.colw[ebase + idx];
   ge_sync();
-  // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row
-  for (int v = tid; v < n; v += nthreads)
+  // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row (complete graphs: scw IS colw)
+  if (!P.complete) for (int v = tid; v < n; v += nthreads)
     for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
       uint16_t e = c.colw[k];
       c.scw[c.rowptr[v] + ge_rank_below(c.abits + v * W, e >> 4)] = e;

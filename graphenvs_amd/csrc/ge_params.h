@@ -57,6 +57,7 @@ struct GeParams {
   int32_t feat_parts;   // n > 64: workgroups sharing one slot's BFS sources in the feature kernel
   int32_t np_early;  // the numpy wave can produce every weight code without the topology (dense delay matrix fits LDS)
   int32_t cost_off;  // DistributionCenter: byte offset of the node-cost list inside the wm scratch
+  uint64_t div_m;    // complete graphs: floor(2^40 / (ng - 1)) + 1, so that idx / (ng - 1) == (idx * div_m) >> 40 for every directed-edge index
   double n_choices;
   double max_distance;  // DistributionCenter coverage radius
   double dt_min, dt_max;  // PerishableProductDelivery delivery-time window
@@ -96,7 +97,7 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
     if (P.env_type == GE_DISTRIBUTION_CENTER) { P.cost_off = matrix; if (P.cost_off + P.n > nb) nb = P.cost_off + P.n; }
     L.wm = take(nb); }
   L.abits = take(P.n * P.W * 8);
-  L.elist = take((P.m > 0 ? P.m : 1) * 4);
+  L.elist = take((P.complete ? P.n : (P.m > 0 ? P.m : 1)) * 4);  // complete graphs have no sampled edge list (only the n-entry path stack of the multicast baseline lives here)
   L.fill = take(P.n * 4);
   L.rowptr = take((P.n + 1) * 4);
   L.colw = take((P.E > 0 ? P.E : 1) * 2);
@@ -126,7 +127,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   L.abits = take(P.n * P.W * 8);
   L.rowptr = take((P.n + 1) * 4);
   L.colw = take((P.E > 0 ? P.E : 1) * 2);
-  L.scw = take((P.E > 0 ? P.E : 1) * 2);
+  L.scw = P.complete ? L.colw : take((P.E > 0 ? P.E : 1) * 2);  // [nx] complete_graph: the rows are already in ascending order
   // the wave count fixes the order of the float64 betweenness partial sums: it is decided from the graph geometry alone (with a
   // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
   const int shared = o + 1024 + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
@@ -137,7 +138,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here
   // complete graph on all nodes (TSP config 3): Brandes is skipped, the workgroup is the pagerank over n rows of n-1 entries --
   // as many waves as fit one workgroup per CU
-  if (P.complete && P.ng == P.n && P.n > 64) { waves = (160 * 1024 - shared) / (per_wave > 0 ? per_wave : 1); if (waves > 8) waves = 8; if (waves < 1) waves = 1; }
+  if (P.complete && P.ng == P.n && P.n > 64) { waves = (P.n + 63) / 64; if (waves > 8) waves = 8; }  // one thread per pagerank row: more waves would only hold LDS
   if (force_waves > 0) waves = force_waves;
   L.waves = waves;
   L.dist = take(waves * P.n * 4);

@@ -215,11 +215,15 @@ GE_DEV int ge_rank_below(const uint64_t *row, int v) {
 
 // source node of directed edge idx
 GE_DEV int ge_row_of(const GeParams &P, const GeRctx &c, int idx) {
-  return P.complete ? idx / (P.ng - 1) : (int)c.tmp[idx];
+  return P.complete ? (int)(((uint64_t)(uint32_t)idx * P.div_m) >> 40) : (int)c.tmp[idx];  // complete: every row has ng - 1 entries
 }
 
 // slot of the directed entry u->v in ascending-neighbour order (no row scan: rank inside the bit row)
 GE_DEV int ge_sorted_pos(const GeRctx &c, int W, int u, int v) { return c.rowptr[u] + ge_rank_below(c.abits + u * W, v); }
+// the same, with the closed form of a complete graph (every node below v except u itself is a neighbour)
+GE_DEV int ge_sorted_pos_p(const GeParams &P, const GeRctx &c, int u, int v) {
+  return P.complete ? c.rowptr[u] + v - (v > u ? 1 : 0) : ge_sorted_pos(c, P.W, u, v);
+}
 
 enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
 
@@ -244,31 +248,56 @@ __device__ unsigned long long ge_stamp_buf[32];
 // accepted sequence gets code 3 + value.  sink 0: nibble matrix wm[k] (k = i*n + j of the delay matrix);
 // sink 1: byte list wm[k]; sink 2: delay[i, j] lands by rank in wsort (needs the topology); sink 3: randint(1, 4) node costs
 // (mask 3, reject > 2; distribution_center.py:82) as a byte list at wm + cost_off.  One wave.
-GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int total, int lane, int sink) {
+// where accepted draw number idx (value val) of a ge_np_draws sequence lands
+GE_DEV void ge_np_sink(const GeParams &P, const GeRctx &c, int sink, int idx, uint32_t val) {
   const int n = P.n, W = P.W;
+  const uint32_t code = (sink == 3 ? 1u : 3u) + val;
+  if (sink == 3) ((uint8_t *)c.wm)[P.cost_off + idx] = (uint8_t)code;
+  else if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
+  else if (sink == 1) ((uint8_t *)c.wm)[idx] = (uint8_t)code;
+  else {
+    const int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
+    if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
+      c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
+    }
+  }
+}
+
+GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int total, int lane, int sink) {
   int base = 0;
+  const uint32_t bm = (sink == 3) ? 3u : 7u;
+  const uint64_t below = (1ull << lane) - 1ull;
   while (base < total) {
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+    // four chunks of 64 raw words at a time while they lie inside the current block and cannot finish the sequence: the four
+    // state reads, tempering chains and ballots are independent, which is what a single wave needs to stay off the LDS latency
+    // (the n x n delay matrix of a 256-node graph is 65 536 accepted draws: 290 us one chunk at a time)
+    if (GE_MT_N - nppos >= 4 * GE_WAVE) {
+      uint32_t val[4]; uint64_t bal[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) val[k] = ge_temper(mt[nppos + GE_WAVE * k + lane]) & bm;
+      int tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { bal[k] = ge_ballot(val[k] < bm); tot += ge_popc64(bal[k]); }
+      if (base + tot < total) {  // wave-uniform
+        int off = base;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (val[k] < bm) ge_np_sink(P, c, sink, off + ge_popc64(bal[k] & below), val[k]);
+          off += ge_popc64(bal[k]);
+        }
+        base = off; nppos += 4 * GE_WAVE;
+        continue;
+      }
+    }
     {
       const int p = nppos + lane; const bool valid = p < GE_MT_N;
-      const uint32_t bm = (sink == 3) ? 3u : 7u;
       const uint32_t val = valid ? (ge_temper(mt[p]) & bm) : 8u;
       const bool acc = valid && val < bm;
       const uint64_t bal = ge_ballot(acc);
-      const int rank = ge_popc64(bal & ((1ull << lane) - 1ull));
+      const int rank = ge_popc64(bal & below);
       const int idx = base + rank;
-      if (acc && idx < total) {
-        const uint32_t code = (sink == 3 ? 1u : 3u) + val;
-        if (sink == 3) ((uint8_t *)c.wm)[P.cost_off + idx] = (uint8_t)code;
-        else if (sink == 0) atomicOr(&c.wm[idx >> 3], code << (4 * (idx & 7)));
-        else if (sink == 1) ((uint8_t *)c.wm)[idx] = (uint8_t)code;
-        else {
-          const int i = (int)((unsigned)idx / (unsigned)n), j = idx - i * n;
-          if (i < j && ((c.abits[i * W + (j >> 6)] >> (j & 63)) & 1ull)) {
-            c.wsort[ge_sorted_pos(c, W, i, j)] = (uint8_t)code; c.wsort[ge_sorted_pos(c, W, j, i)] = (uint8_t)code;
-          }
-        }
-      }
+      if (acc && idx < total) ge_np_sink(P, c, sink, idx, val);
       const int nacc = ge_popc64(bal);
       if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
         const int need = total - base - 1;
@@ -1097,7 +1126,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     ge_wave_sync();
   } else if (P.complete) {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
-      int u = idx / (ng - 1), k = idx % (ng - 1);
+      const int u = ge_row_of(P, c, idx), k = idx - u * (ng - 1);
       int v = k < u ? k : k + 1;
       c.colw[idx] = (uint16_t)((v << 4) | 10);
     }
@@ -1138,7 +1167,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
       for (int idx = lane; idx < E; idx += GE_WAVE) {
         int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
         int a = u < v ? u : v, b = u < v ? v : u, cell = a * n + b;
-        c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u);
+        c.wsort[ge_sorted_pos_p(P, c, u, v)] = (uint8_t)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u);
       }
     } else if (P.spatial) {  // tsp.py:85-86: Euclidean distance, float64, stored in ascending-neighbour order
       const double *xy = (const double *)(c.wm + 4 * n);
@@ -1146,7 +1175,15 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
         int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
         int a = u < v ? u : v, b = u < v ? v : u;  // G.edges yields (min, max)
         double dx = xy[2 * a] - xy[2 * b], dy = xy[2 * a + 1] - xy[2 * b + 1];
-        P.buf.sw64[ebase + ge_sorted_pos(c, W, u, v)] = __builtin_sqrt(dx * dx + dy * dy);
+        P.buf.sw64[ebase + ge_sorted_pos_p(P, c, u, v)] = __builtin_sqrt(dx * dx + dy * dy);
+      }
+    } else if (P.weighted && t == GE_TSP && P.complete) {
+      // complete graph ([nx] complete_graph = combinations(nodes, 2)): G.edges is (0,1) (0,2) .. (0,n-1) (1,2) ..., so the edge
+      // (a, b), a < b, is draw number a (n - 1) - a (a - 1) / 2 + (b - a - 1): no scan over the edge list
+      for (int idx = lane; idx < E; idx += GE_WAVE) {
+        const int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+        const int a = u < v ? u : v, b = u < v ? v : u;
+        c.wsort[ge_sorted_pos_p(P, c, u, v)] = ((const uint8_t *)c.wm)[a * (ng - 1) - ((a * (a - 1)) >> 1) + (b - a - 1)];
       }
     } else if (P.weighted && t == GE_TSP) {  // k-th edge of G.edges (u ascending, insertion order, v > u) gets draw k
       int carry = 0;
@@ -1173,7 +1210,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     ge_wave_sync();
     for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
-      c.colw[idx] = (uint16_t)((v << 4) | c.wsort[ge_sorted_pos(c, W, u, v)]);
+      c.colw[idx] = (uint16_t)((v << 4) | c.wsort[ge_sorted_pos_p(P, c, u, v)]);
     }
     ge_wave_sync();
     GE_STAMP(5);
@@ -1185,7 +1222,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   } else {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
-      c.wsort[ge_sorted_pos(c, W, u, v)] = (uint8_t)(c.colw[idx] & 15);
+      c.wsort[ge_sorted_pos_p(P, c, u, v)] = (uint8_t)(c.colw[idx] & 15);
     }
     ge_wave_sync();
     if (path_like_t || t == GE_DISTRIBUTION_CENTER || t == GE_PERISHABLE_DELIVERY) {
@@ -1295,7 +1332,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     G.edge_index[ebase + idx] = P.node_id_base + nbase + u;
     G.edge_index[Ne + ebase + idx] = P.node_id_base + nbase + v;
     float wv = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 1.f : (float)ge_wlut(code);
-    if (P.spatial) wv = (float)G.sw64[ebase + ge_sorted_pos(c, W, u, v)];
+    if (P.spatial) wv = (float)G.sw64[ebase + ge_sorted_pos_p(P, c, u, v)];
     if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
     else G.edge_attr[ebase + idx] = wv;
     G.colw[ebase + idx] = c.colw[idx];

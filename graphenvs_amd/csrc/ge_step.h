@@ -104,7 +104,10 @@ GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
 // RAGGED (multi-class engine): PG is the engine-wide block (B = all slots, the reset queue); every thread looks up its slot's class
 // and runs that class's transition on the class-local slot index -- P then lives in memory (per-lane loads), which the reset-
 // dominated ragged workloads can afford.  Mask bytes are written by the slot's own thread (the classes' mask widths differ).
-template <int ENV, bool SAMPLE, bool RAGGED>
+// PRUNE: parenting >= 2 of LongestPath / TSP (per-thread walks of the residual graph over node sets of up to GE_MAXW words, ~64
+// registers of scratch sets): its own instantiation, so that the plain transitions (BASELINE config 3 runs TSP with parenting 1)
+// do not carry those registers.
+template <int ENV, bool SAMPLE, bool RAGGED, bool PRUNE>
 GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t policy_seed) {
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -162,20 +165,22 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
           head_out = a;
           G.x[(nbase + a) * F + 0] = 1.f;
           uint64_t any = 0;
-          uint64_t alive[GE_MAXW], R[GE_MAXW];
+          uint64_t alive[PRUNE ? GE_MAXW : 1], R[PRUNE ? GE_MAXW : 1];
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
-            if (w < GE_MAXW) alive[w] = ge_full_word(n, w) & ~vb;
+            if (PRUNE && w < GE_MAXW) alive[w] = ge_full_word(n, w) & ~vb;
           }
-          const bool prune = lp && P.parenting >= 2 && a != dest;  // longest_path.py:134-143 (dest still in alt_G)
-          if (prune) ge_reach_thread(G.adj_bits + nbase * W, W, alive, dest, -1, R);
+          const bool prune = PRUNE && lp && P.parenting >= 2 && a != dest;  // longest_path.py:134-143 (dest still in alt_G)
           int n_alive = 0;
-          if (lp && P.parenting == 3) for (int w = 0; w < W; w++) n_alive += ge_popc64(alive[w]);
+          if constexpr (PRUNE) {
+            if (prune) ge_reach_thread(G.adj_bits + nbase * W, W, alive, dest, -1, R);
+            if (lp && P.parenting == 3) for (int w = 0; w < W; w++) n_alive += ge_popc64(alive[w]);
+          }
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             uint64_t nm = (lp && P.parenting == 0) ? ge_full_word(A, w) : (G.adj_bits[(nbase + a) * W + w] & ~vb);
-            if (prune) { nm &= R[w]; if (P.parenting == 3 && n_alive <= n / 3) nm |= alive[w]; }
+            if constexpr (PRUNE) { if (prune) { nm &= R[w]; if (P.parenting == 3 && n_alive <= n / 3) nm |= alive[w]; } }
             stage[tid * WS + w] = nm; any |= nm;
           }
           wrote_mask = !(lp && P.parenting == 0);
@@ -207,7 +212,7 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
             if (taken < n - 1 && w == 0) nm &= ~1ull;  // start only once everything else is taken (tsp.py:178-179)
             stage[tid * WS + w] = nm; any |= nm;
           }
-          if (P.parenting >= 2 && any) {  // tsp.py:181-194: a move must leave the untaken nodes (start excluded) connected
+          if constexpr (PRUNE) if (P.parenting >= 2 && any) {  // tsp.py:181-194: a move must leave the untaken nodes (start excluded) connected
             uint64_t alive[GE_MAXW], R[GE_MAXW];
             int n_alive = 0;
             for (int w = 0; w < W; w++) {

@@ -1,15 +1,23 @@
-# refresh the judged evidence: bench line, kernel trace stats + medians, PMC traffic.  usage (GPU box): bash tools/collect_profiles.sh <tag>
-set -e
-TAG=${1:-r01_x}
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+# refresh the judged evidence of a round.  usage (GPU box): bash tools/collect_profiles.sh <tag, e.g. r02>
+# -> gpurun_out/<tag>_prof/: c2 SQ + TCC counters and kernel trace (bench loop), 1 M-slot step-kernel traffic, c3 / c4 traces and
+#    bench lines, the config-5 line; tools/make_pmc_summary.py then writes profiles/<tag>_pmc_summary.json
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}_prof; mkdir -p $O
+bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/c2 bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-1m > $O/c2_passes.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch --output-format csv -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write --output-format csv -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/pmc_write.log 2>&1
-python3 $R/tools/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_step_kernel.json
-cp $O/pmc_step_kernel.json $R/profiles/pmc_step_kernel.json
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.log
-cp $(ls $O/trace/*/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
-python3 $R/tools/kstats.py $O/trace > $O/kernel_medians.txt
-cd $R && timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
-cat $O/bench.json; cat $O/kernel_medians.txt
-rm -rf $O/pmc_fetch $O/pmc_write $O/trace
+export GE_B=1048576 GE_REPS=3
+for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_COUNT"; do
+  n=$(echo $set | cut -d' ' -f1)
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace -d $O/m1_$n --output-format csv -- python3 $R/tools/step_loop.py > $O/m1_$n.log 2>&1 || echo "1m $n failed"
+done
+python3 $R/tools/pmc_summary.py $O/m1_FETCH_SIZE $O/m1_WRITE_SIZE --kernel step_path64 > $O/step_1m_traffic.txt 2>&1
+rm -rf $O/m1_FETCH_SIZE $O/m1_WRITE_SIZE
+for cfg in c3 c4; do
+  bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/$cfg bench.py --config $cfg --steps 130 --warmup 5 --no-cpu-baseline > $O/${cfg}_passes.log 2>&1
+done
+cd $R
+timeout -k 10 400 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
+timeout -k 10 300 python3 bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
+timeout -k 10 300 python3 bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+timeout -k 10 400 python3 tools/bench_configs.py c5 mis ds mc dc ppd > $O/other_configs.jsonl 2> $O/other_configs.err
+cat $O/c2/kernel_medians.txt; cut -c1-200 $O/bench_c2.json; cat $O/other_configs.jsonl
