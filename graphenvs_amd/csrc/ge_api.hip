@@ -341,7 +341,7 @@ static int launch_features(ge_engine *e, int mode, void *stream) {
     if (rc != GE_OK) return rc;
     // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64, feat_parts workgroups each
     if (rg) {
-      int64_t want = (int64_t)e->gen_grid * e->P.feat_parts * (mode == GE_RESET_QUEUE ? 1 : 4);
+      int64_t want = (int64_t)e->gen_grid * ge_feat_workgroups(e->P.feat_parts) * (mode == GE_RESET_QUEUE ? 1 : 4);
       if (want > 65535 * 16) want = 65535 * 16;
       GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
       rc = check_launch("feature kernel (list)");
@@ -352,8 +352,8 @@ static int launch_features(ge_engine *e, int mode, void *stream) {
     return check_launch("feature kernel (fallback list)");
   }
   {
-    int64_t want = (int64_t)fgrid * e->P.feat_parts;
-    if (mode == GE_RESET_QUEUE && want > 4096) want = 4096;  // queue mode: the list is short, workgroups stride over it
+    int64_t want = (int64_t)fgrid * ge_feat_workgroups(e->P.feat_parts);
+    if (mode == GE_RESET_QUEUE && want > 4608) want = 4608;  // queue mode: the list is short, workgroups stride over it
     if (want > 65535 * 16) want = 65535 * 16;
     if (rg) GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);
     else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);

@@ -35,7 +35,10 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
 
 // Any n.  The workgroup has 1..8 waves (whatever fits LDS): the graph is staged once, then every wave runs the
 // level-synchronous Brandes pass for its own sources (s = wave, wave + waves, ...) on private scratch; per-wave
-// betweenness partial sums are combined in wave order, then wave 0 does clustering and pagerank.
+// betweenness partial sums are combined in wave order, then clustering and pagerank.
+// nparts > 1: the slot's BFS sources are dealt over nparts workgroups (part 0 .. nparts-1), and ONE MORE workgroup
+// (part == nparts) does the node-level work -- clustering, pagerank, degrees -- beside them instead of behind one of them.
+GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat_parts + 1 : 1; }
 GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid_fresh(), nthreads = ge_bdim();
   const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
@@ -59,13 +62,15 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   // Brandes betweenness + closeness: one level-synchronous BFS per source, sources dealt round-robin to the waves
   // complete graph on all n nodes (TSP config 3): every pair is adjacent, so no shortest path has an interior node
   // (betweenness is a sum of zeros) and every BFS has one level of n-1 nodes (closeness (n-1)/(n-1) * (n-1)/(n-1))
-  const bool trivial = P.complete && P.ng == n;
-  if (trivial) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
+  const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
+  const bool trivial = (P.complete && P.ng == n) || node_part;
+  if (trivial && !node_part) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
   for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
     for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
     ge_wave_sync();
     int d = 0, reach = 1; int64_t tot = 0;
-    for (;;) {  // forward: discover level d+1, sigma by pull from level d
+    for (;;) {  // forward: discover level d+1, sigma by pull from level d (a push by the frontier with ds_add_f64 was measured
+      // slower: C4 feature kernel 501 -> 560 us)
       // a node moves from -1 to d+1, never to d, so lanes still testing dist[u] == d are unaffected
       uint64_t any = 0; int found = 0;
       for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
@@ -106,10 +111,12 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   if (nparts > 1) {
     // several workgroups share this slot's sources (few slots, many CUs): closeness of the own sources is final, the
     // betweenness partial goes to scratch and ge_k_feat_combine adds the parts in part order
-    for (int v = tid; v < n; v += nthreads) G.feat_scratch[((int64_t)env * nparts + part) * n + v] = c.bc[v];
-    for (int v = tid; v < n; v += nthreads) if ((v % (nwaves * nparts)) / nwaves == part) G.x[(nbase + v) * F + P.nflag + 2] = (float)c.clos[v];
-    ge_sync();
-    if (part != 0) return;  // part 0 also does clustering and pagerank
+    if (!node_part) {
+      for (int v = tid; v < n; v += nthreads) G.feat_scratch[((int64_t)env * nparts + part) * n + v] = c.bc[v];
+      for (int v = tid; v < n; v += nthreads) if ((v % (nwaves * nparts)) / nwaves == part) G.x[(nbase + v) * F + P.nflag + 2] = (float)c.clos[v];
+      ge_sync();
+      return;
+    }
   }
   // node-level work, rows dealt to every thread of the workgroup (each node's sums keep their order; the iteration count and
   // the pairwise error sum are the same in every wave)
@@ -180,10 +187,13 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
 #define GE_F64_SS 66   // u16 stride of a sigma row  (33 dwords: odd, spreads banks)
 #define GE_F64_SD 65   // f64 stride of a delta row
 
-struct GeF64 { uint64_t *abits, *lvl; uint16_t *sig; double *del, *x, *y, *sinv, *diff, *clos; uint8_t *scode; };
+#ifndef GE_F64_INV
+#define GE_F64_INV 128  // reciprocals 1/k kept in LDS for the path counts k < GE_F64_INV (larger counts divide)
+#endif
+struct GeF64 { uint64_t *abits, *lvl; uint16_t *sig; double *del, *x, *y, *sinv, *diff, *clos, *inv; uint8_t *scode; };
 
 GE_HOSTDEV int ge_f64_bytes(int E, int tsp, int nblk) {
-  int o = 512 + GE_F64_LV * 512 + 64 * GE_F64_SS * 2 + 64 * GE_F64_SD * 8 + 5 * 512;
+  int o = 512 + GE_F64_LV * 512 + 64 * GE_F64_SS * 2 + 64 * GE_F64_SD * 8 + 5 * 512 + GE_F64_INV * 8;
   o = (o + 15) & ~15;
   if (tsp) o += (E + 15) & ~15;
   return o + (nblk + 2) * 4 + 16;
@@ -196,6 +206,7 @@ GE_DEV GeF64 ge_carve_f64(int E, int tsp) {
   c.lvl = (uint64_t *)s; s += GE_F64_LV * 512;
   c.del = (double *)s; s += 64 * GE_F64_SD * 8;
   c.x = (double *)s; s += 512; c.y = (double *)s; s += 512; c.sinv = (double *)s; s += 512; c.diff = (double *)s; s += 512; c.clos = (double *)s; s += 512;
+  c.inv = (double *)s; s += GE_F64_INV * 8;
   c.sig = (uint16_t *)s; s += 64 * GE_F64_SS * 2;
   c.scode = (uint8_t *)(((uintptr_t)s + 15) & ~(uintptr_t)15);
   return c;
@@ -210,6 +221,9 @@ GE_HOSTDEV int ge_f64_pre_off(int E, int tsp, int nblk) { return ge_f64_bytes(E,
 // 16-bit counters are appended to work_list for the generic kernel.
 #ifndef GE_F64_QL
 #define GE_F64_QL 4  // lanes per BFS source (4 = quad: 16 sources per wave, 4 walker waves; 2 = pair: 32 per wave, 2 waves)
+#endif
+#ifndef GE_F64_K
+#define GE_F64_K 3   // nodes of a level a quad handles per walk iteration (measured on the headline config: 2: 248 us, 3: 242 us, 4: 244 us)
 #endif
 #define GE_F64_WALKERS (64 * GE_F64_QL)
 #define GE_F64_THREADS (GE_F64_WALKERS + 64)
@@ -239,6 +253,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   for (int i = tid; i < 64 * GE_F64_SS / 2; i += GE_F64_THREADS) ((uint32_t *)c.sig)[i] = 0u;
   for (int i = tid; i < 64 * GE_F64_SD; i += GE_F64_THREADS) c.del[i] = 0.0;
   if (prw) for (int i = tid; i < E; i += GE_F64_THREADS) c.scode[i] = G.scode[ebase + i];
+  for (int i = tid; i < GE_F64_INV; i += GE_F64_THREADS) c.inv[i] = 1.0 / (double)(i > 0 ? i : 1);  // correctly rounded reciprocals
   ge_sync();
 
   GE_STAMP(12);
@@ -273,23 +288,33 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
         cur = nxt; nxt = 0;
       }
       ge_quad_sync();  // the quad's pushes of the previous nodes are in LDS before these nodes are read
-      // two nodes of the current level per iteration: their counts are final, their pushes are commutative adds
-      const int u = ge_ctz64(cur); cur &= cur - 1;
-      const bool two = cur != 0;
-      const int u2 = two ? ge_ctz64(cur) : u; cur &= cur - 1;
-      const uint32_t su = c.sig[u * GE_F64_SS + s], su2 = c.sig[u2 * GE_F64_SS + s];
-      if ((su | su2) > 1023u) ovf = true;            // 64 parents x 1023 still fit the 16-bit counters
-      uint64_t cand = c.abits[u] & ~visited, cand2 = two ? (c.abits[u2] & ~visited) : 0ull;
-      nxt |= cand | cand2;
-      // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
-      ge_slice_t mine = (ge_slice_t)(cand >> ((GE_F64_SLICE * q) & 63)) & slice_mask, mine2 = (ge_slice_t)(cand2 >> ((GE_F64_SLICE * q) & 63)) & slice_mask;
-      const uint32_t add1 = su << sig_sh, add2 = su2 << sig_sh;
-      while (mine | mine2) {
-        if (mine) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
-          ge_lds_add_u32(sig_mine + GE_SLICE_CTZ(mine) * (GE_F64_SS / 2), add1); mine &= mine - 1;
-        }
-        if (mine2) {
-          ge_lds_add_u32(sig_mine + GE_SLICE_CTZ(mine2) * (GE_F64_SS / 2), add2); mine2 &= mine2 - 1;
+      // GE_F64_K nodes of the current level per iteration: their counts are final, their pushes are commutative adds, and the K
+      // reads / push streams are independent of each other (the fixed cost of an iteration is shared, the LDS round trips overlap)
+      int u[GE_F64_K]; bool has[GE_F64_K];
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) { has[k] = cur != 0; u[k] = has[k] ? ge_ctz64(cur) : u[0]; cur &= cur - 1; }
+      uint32_t su[GE_F64_K]; uint64_t ab[GE_F64_K];
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) { su[k] = c.sig[u[k] * GE_F64_SS + s]; ab[k] = c.abits[u[k]]; }
+      uint32_t any_su = 0; ge_slice_t mine[GE_F64_K], any_mine = 0;
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) {
+        any_su |= su[k];
+        const uint64_t cand = has[k] ? (ab[k] & ~visited) : 0ull;
+        nxt |= cand;
+        // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
+        mine[k] = (ge_slice_t)(cand >> ((GE_F64_SLICE * q) & 63)) & slice_mask; any_mine |= mine[k];
+        su[k] <<= sig_sh;
+      }
+      if (any_su > 1023u) ovf = true;            // 64 parents x 1023 still fit the 16-bit counters
+      while (any_mine) {
+        any_mine = 0;
+#pragma unroll
+        for (int k = 0; k < GE_F64_K; k++) {
+          if (mine[k]) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
+            ge_lds_add_u32(sig_mine + GE_SLICE_CTZ(mine[k]) * (GE_F64_SS / 2), su[k]); mine[k] &= mine[k] - 1;
+          }
+          any_mine |= mine[k];
         }
       }
     }
@@ -352,22 +377,36 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
         continue;
       }
       ge_quad_sync();
-      // two nodes of the level per iteration (independent division chains overlap).  del[w] holds S(w) = sum of
+      // GE_F64_K nodes of the level per iteration (independent division chains overlap).  del[w] holds S(w) = sum of
       // coeff over w's DAG successors (deeper level, finished); delta(w) = sigma(w) * S(w) and coeff(w) =
       // (1 + delta(w)) / sigma(w) is pushed to w's predecessors.  S stays in del[]: the betweenness reduction
       // multiplies by sigma again, so nothing is rewritten here.
-      const int w = ge_ctz64(cur); cur &= cur - 1;
-      const bool two = cur != 0;
-      const int w2 = two ? ge_ctz64(cur) : w; cur &= cur - 1;
-      const double sg = (double)c.sig[w * GE_F64_SS + s], sg2 = (double)c.sig[w2 * GE_F64_SS + s];
-      const double coeff = (1.0 + sg * c.del[w * GE_F64_SD + s]) / sg, coeff2 = (1.0 + sg2 * c.del[w2 * GE_F64_SD + s]) / sg2;
-      uint64_t pb = c.abits[w] & prev, pb2 = two ? (c.abits[w2] & prev) : 0ull;
-      // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same
-      // lane, w before w2, iteration after iteration: the float64 sum order is fixed
-      ge_slice_t mine = (ge_slice_t)(pb >> ((GE_F64_SLICE * q) & 63)) & slice_mask, mine2 = (ge_slice_t)(pb2 >> ((GE_F64_SLICE * q) & 63)) & slice_mask;
-      while (mine | mine2) {
-        if (mine) { ge_lds_add_f64(del_mine + GE_SLICE_CTZ(mine) * GE_F64_SD, coeff); mine &= mine - 1; }  // ds_add_f64
-        if (mine2) { ge_lds_add_f64(del_mine + GE_SLICE_CTZ(mine2) * GE_F64_SD, coeff2); mine2 &= mine2 - 1; }
+      int w[GE_F64_K]; bool has[GE_F64_K];
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) { has[k] = cur != 0; w[k] = has[k] ? ge_ctz64(cur) : w[0]; cur &= cur - 1; }
+      uint32_t sg[GE_F64_K]; double S[GE_F64_K], rs[GE_F64_K]; uint64_t ab[GE_F64_K];
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) { sg[k] = c.sig[w[k] * GE_F64_SS + s]; S[k] = c.del[w[k] * GE_F64_SD + s]; ab[k] = c.abits[w[k]]; }
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) rs[k] = c.inv[sg[k] < GE_F64_INV ? sg[k] : 0u];
+      double coeff[GE_F64_K]; ge_slice_t mine[GE_F64_K], any_mine = 0;
+#pragma unroll
+      for (int k = 0; k < GE_F64_K; k++) {
+        // coeff(w) = (1 + delta(w)) / sigma(w) with delta(w) = sigma(w) S(w), i.e. 1 / sigma(w) + S(w): the reciprocal of the
+        // (small, integer) path count comes from the LDS table, one float64 add instead of a multiply, an add and a division
+        coeff[k] = (sg[k] < GE_F64_INV ? rs[k] : 1.0 / (double)sg[k]) + S[k];
+        const uint64_t pb = has[k] ? (ab[k] & prev) : 0ull;
+        // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same lane, in the
+        // same interleaving of the K push streams, iteration after iteration: the float64 sum order is fixed
+        mine[k] = (ge_slice_t)(pb >> ((GE_F64_SLICE * q) & 63)) & slice_mask; any_mine |= mine[k];
+      }
+      while (any_mine) {
+        any_mine = 0;
+#pragma unroll
+        for (int k = 0; k < GE_F64_K; k++) {
+          if (mine[k]) { ge_lds_add_f64(del_mine + GE_SLICE_CTZ(mine[k]) * GE_F64_SD, coeff[k]); mine[k] &= mine[k] - 1; }  // ds_add_f64
+          any_mine |= mine[k];
+        }
       }
     }
   }
@@ -421,7 +460,8 @@ GE_KERNEL ge_k_features(GeParams P, GeRagged R, int mode, int pre_off) {
   }
   // workgroups per item: the uniform engine's fallback list is rare and small (one workgroup each); the multi-class engine sends
   // every slot of a class with n > 64 through the list, feat_parts workgroups each (P.feat_parts = the largest class's)
-  const int nparts = (mode == GE_FEAT_LIST && !RAGGED) ? 1 : P.feat_parts;
+  const int fparts = (mode == GE_FEAT_LIST && !RAGGED) ? 1 : P.feat_parts;
+  const int nparts = ge_feat_workgroups(fparts);  // workgroups per item (engine-wide: the largest class's)
   for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
     const int item = q / nparts, part = q % nparts;
     const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
@@ -429,9 +469,9 @@ GE_KERNEL ge_k_features(GeParams P, GeRagged R, int mode, int pre_off) {
     if constexpr (RAGGED) {
       const int cls = ge_slot_class(R, env);
       const GeParams &C = R.classes[cls];
-      if (part < C.feat_parts) ge_features_generic_env(C, env - R.class_start[cls], part, C.feat_parts);  // uniform per workgroup
+      if (part < ge_feat_workgroups(C.feat_parts)) ge_features_generic_env(C, env - R.class_start[cls], part, C.feat_parts);  // uniform per workgroup
     } else {
-      ge_features_generic_env(P, env, part, nparts);
+      ge_features_generic_env(P, env, part, fparts);
     }
   }
 }
