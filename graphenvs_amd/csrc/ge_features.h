@@ -263,7 +263,6 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   // served in parallel while the per-source order of the float64 delta sums stays fixed.
   const int s = (tid >> 6) * (64 / GE_F64_QL) + ((tid & 63) / GE_F64_QL);
   const int q = tid & (GE_F64_QL - 1);
-  const ge_slice_t slice_mask = (GE_F64_SLICE >= 32) ? (ge_slice_t)~(ge_slice_t)0 : (ge_slice_t)((1u << (GE_F64_SLICE & 31)) - 1u);
   const bool walker = !node_wave && s < n;
   // push targets of this lane: node (SLICE q + b), b = bit inside the slice.  The sigma counters are half-words, two to a dword;
   // a row is GE_F64_SS (even) half-words, so the dword of (node, s) is row * SS/2 + (s >> 1) and the half inside it depends on s
@@ -275,17 +274,23 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   bool ovf = false;
   int D = 0, reach = 1; int64_t tot = 0;
   GE_STAMP_T0(24);
+  static_assert(GE_F64_QL == 4, "the walk keeps the visited / next-level sets as 16-bit slices, one per lane of a quad");
+  const uint16_t *const adj_mine = (const uint16_t *)c.abits + q;  // this lane's 16 columns of an adjacency row: adj_mine[4 u]
   if (walker) {
-    uint64_t visited = 1ull << s, cur = visited, nxt = 0;
+    // the lane only ever pushes to the nodes of its own slice, so it keeps just that slice of the visited set and of the level being
+    // discovered (one 32-bit operation where the whole sets took two); the quad assembles the whole next level once per level
+    uint64_t cur = 1ull << s;
+    uint32_t vis16 = (uint32_t)((1ull << s) >> (16 * q)) & 0xffffu, nxt16 = 0u;
     if (q == 0) c.sig[s * GE_F64_SS + s] = 1;
     for (;;) {
       if (cur == 0) {
+        const uint64_t nxt = ge_quad_gather16(nxt16);
         if (!nxt) break;
-        visited |= nxt; D++;
+        vis16 |= nxt16; D++;
         if (D < GE_F64_LV) { if (q == 0) c.lvl[D * 64 + s] = nxt; } else ovf = true;
         const int cnt = ge_popc64(nxt);
         reach += cnt; tot += (int64_t)D * cnt;
-        cur = nxt; nxt = 0;
+        cur = nxt; nxt16 = 0u;
       }
       ge_quad_sync();  // the quad's pushes of the previous nodes are in LDS before these nodes are read
       // GE_F64_K nodes of the current level per iteration: their counts are final, their pushes are commutative adds, and the K
@@ -293,19 +298,19 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
       int u[GE_F64_K]; bool has[GE_F64_K];
 #pragma unroll
       for (int k = 0; k < GE_F64_K; k++) { has[k] = cur != 0; u[k] = has[k] ? ge_ctz64(cur) : u[0]; cur &= cur - 1; }
-      uint32_t su[GE_F64_K]; uint64_t ab[GE_F64_K];
+      uint32_t su[GE_F64_K], ab[GE_F64_K];
 #pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) { su[k] = c.sig[u[k] * GE_F64_SS + s]; ab[k] = c.abits[u[k]]; }
+      for (int k = 0; k < GE_F64_K; k++) { su[k] = c.sig[u[k] * GE_F64_SS + s]; ab[k] = adj_mine[4 * u[k]]; }
       uint32_t any_su = 0; ge_slice_t mine[GE_F64_K], any_mine = 0;
+      const uint32_t open16 = ~vis16;
 #pragma unroll
       for (int k = 0; k < GE_F64_K; k++) {
         any_su |= su[k];
-        const uint64_t cand = has[k] ? (ab[k] & ~visited) : 0ull;
-        nxt |= cand;
         // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
-        mine[k] = (ge_slice_t)(cand >> ((GE_F64_SLICE * q) & 63)) & slice_mask; any_mine |= mine[k];
+        mine[k] = has[k] ? (ab[k] & open16) : 0u; any_mine |= mine[k];
         su[k] <<= sig_sh;
       }
+      nxt16 |= any_mine;
       if (any_su > 1023u) ovf = true;            // 64 parents x 1023 still fit the 16-bit counters
       while (any_mine) {
         any_mine = 0;
@@ -339,6 +344,11 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   const uint64_t dangling = ge_ballot(live && deg == 0);
   x = pinit;
   c.sinv[lane] = sinv;
+  // the 16 smallest neighbours as byte indices in four registers: the pull of an iteration becomes 16 unrolled (predicated) LDS
+  // reads and adds in ascending-neighbour order instead of a ctz / clear-lowest-bit loop of max-degree trips; `rest` = what is left
+  // of a row with more than 16 neighbours
+  uint32_t nb4[4] = {0u, 0u, 0u, 0u}; uint64_t rest = adj;
+  { int k = 0; for (; rest && k < 16; rest &= rest - 1, k++) nb4[k >> 2] |= (uint32_t)ge_ctz64(rest) << (8 * (k & 3)); }
   bool conv = false;
   for (int it = 0; it < 100 && !conv; it++) {
     c.x[lane] = x; c.y[lane] = sinv * x;  // unweighted: data'[j->i] * x[j] is the same product for every i
@@ -349,7 +359,11 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
     if (live) {
       double acc = 0.0;
       if (prw) { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) { const int j = ge_ctz64(r); acc += (c.sinv[j] * ge_wlut(c.scode[rp + k])) * c.x[j]; } }
-      else for (uint64_t r = adj; r; r &= r - 1) acc += c.y[ge_ctz64(r)];
+      else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const double yv = c.y[(nb4[k >> 2] >> (8 * (k & 3))) & 63u]; acc += (k < deg) ? yv : 0.0; }  // x + 0.0 == x
+        for (uint64_t r = rest; r; r &= r - 1) acc += c.y[ge_ctz64(r)];
+      }
       xn = alpha * (acc + dsum * pinit) + oma * pinit;
     }
     c.diff[lane] = live ? __builtin_fabs(xn - x) : 0.0;
@@ -370,10 +384,11 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
     int d = D;
     uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
     uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
+    uint32_t prev16 = (uint32_t)(prev >> (16 * q)) & 0xffffu;  // this lane's slice of the level above
     while (d >= 1) {
       if (cur == 0) {
         d--;
-        if (d >= 1) { cur = c.lvl[d * 64 + s]; prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s); }
+        if (d >= 1) { cur = c.lvl[d * 64 + s]; prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s); prev16 = (uint32_t)(prev >> (16 * q)) & 0xffffu; }
         continue;
       }
       ge_quad_sync();
@@ -384,9 +399,9 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
       int w[GE_F64_K]; bool has[GE_F64_K];
 #pragma unroll
       for (int k = 0; k < GE_F64_K; k++) { has[k] = cur != 0; w[k] = has[k] ? ge_ctz64(cur) : w[0]; cur &= cur - 1; }
-      uint32_t sg[GE_F64_K]; double S[GE_F64_K], rs[GE_F64_K]; uint64_t ab[GE_F64_K];
+      uint32_t sg[GE_F64_K], ab[GE_F64_K]; double S[GE_F64_K], rs[GE_F64_K];
 #pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) { sg[k] = c.sig[w[k] * GE_F64_SS + s]; S[k] = c.del[w[k] * GE_F64_SD + s]; ab[k] = c.abits[w[k]]; }
+      for (int k = 0; k < GE_F64_K; k++) { sg[k] = c.sig[w[k] * GE_F64_SS + s]; S[k] = c.del[w[k] * GE_F64_SD + s]; ab[k] = adj_mine[4 * w[k]]; }
 #pragma unroll
       for (int k = 0; k < GE_F64_K; k++) rs[k] = c.inv[sg[k] < GE_F64_INV ? sg[k] : 0u];
       double coeff[GE_F64_K]; ge_slice_t mine[GE_F64_K], any_mine = 0;
@@ -395,10 +410,9 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
         // coeff(w) = (1 + delta(w)) / sigma(w) with delta(w) = sigma(w) S(w), i.e. 1 / sigma(w) + S(w): the reciprocal of the
         // (small, integer) path count comes from the LDS table, one float64 add instead of a multiply, an add and a division
         coeff[k] = (sg[k] < GE_F64_INV ? rs[k] : 1.0 / (double)sg[k]) + S[k];
-        const uint64_t pb = has[k] ? (ab[k] & prev) : 0ull;
         // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same lane, in the
         // same interleaving of the K push streams, iteration after iteration: the float64 sum order is fixed
-        mine[k] = (ge_slice_t)(pb >> ((GE_F64_SLICE * q) & 63)) & slice_mask; any_mine |= mine[k];
+        mine[k] = has[k] ? (ab[k] & prev16) : 0u; any_mine |= mine[k];
       }
       while (any_mine) {
         any_mine = 0;

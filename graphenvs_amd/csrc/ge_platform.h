@@ -37,6 +37,12 @@ GE_DEV void ge_quad_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront
 // value of the lane (lane ^ 1) / (lane ^ 2) inside the quad: one DPP move (quad_perm), no LDS
 GE_DEV uint32_t ge_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }
 GE_DEV uint32_t ge_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }
+// the 16-bit values of the four lanes of a quad as one 64-bit word (lane k of the quad in bits [16k, 16k+16)): four quad_perm broadcasts
+GE_DEV uint64_t ge_quad_gather16(uint32_t v) {
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true), b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true);
+  const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, true), b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true);
+  return (uint64_t)((b0 & 0xffffu) | (b1 << 16)) | ((uint64_t)((b2 & 0xffffu) | (b3 << 16)) << 32);
+}
 // fire-and-forget LDS adds (ds_add_u32 / ds_add_f64, no return value, nothing to wait for)
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 GE_DEV void ge_lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }

@@ -207,6 +207,17 @@ GE_DEV uint32_t ge_quad_xchg(uint32_t v, int xr) {
   ge_quad_sync();
   return r;
 }
+GE_DEV uint64_t ge_quad_gather16(uint32_t v) {
+  ge_emu::Block &b = ge_emu::blk();
+  static uint32_t gslot[ge_emu::kMaxThreads];
+  gslot[b.cur] = v;
+  const int q0 = b.cur & ~3;
+  ge_quad_sync();
+  uint64_t r = 0;
+  for (int k = 0; k < 4; k++) r |= (uint64_t)(gslot[q0 + k] & 0xffffu) << (16 * k);
+  ge_quad_sync();
+  return r;
+}
 GE_DEV uint32_t ge_quad_xor1(uint32_t v) { return ge_quad_xchg(v, 1); }
 GE_DEV uint32_t ge_quad_xor2(uint32_t v) { return ge_quad_xchg(v, 2); }
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
