@@ -1045,17 +1045,16 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
       }
       ge_wave_sync();
       if (failed) break;
-      bool ok = ge_connected(c, ng, W, -1, lane);
-      if (ok && t == GE_TSP) {  // tsp.py:65-71
-        uint64_t deg1 = 0;
-        for (int k = 0; k < W; k++) {
-          int v = k * GE_WAVE + lane; int d = 0;
-          if (v < n) for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]);
-          deg1 |= ge_ballot(v < n && d == 1);
-        }
-        ok = !deg1;
-        if (ok) ok = ge_connected(c, ng, W, 0, lane);
+      // most disconnected G(n, m) samples have an isolated node (TSP also rejects a node of degree 1, tsp.py:65-68): one pass over
+      // the degrees settles those attempts without the BFS; the launch lasts as long as its unluckiest slot's attempts
+      uint64_t low = 0;
+      for (int k = 0; k < W; k++) {
+        const int v = k * GE_WAVE + lane; int d = 0;
+        if (v < ng) for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]);
+        low |= ge_ballot(v < ng && (d == 0 || (t == GE_TSP && d == 1)));
       }
+      bool ok = !low && ge_connected(c, ng, W, -1, lane);
+      if (ok && t == GE_TSP) ok = ge_connected(c, ng, W, 0, lane);  // tsp.py:69-71
       if (ok && t == GE_PERISHABLE_DELIVERY) {  // perishable_product_delivery.py:75-111: weights and placement belong to the attempt
         double rnd;
         if (ppd_attempt == 0) { ge_sync(); ppd_pos = c.misc[2]; rnd = *(const double *)c.misc; }  // join: the numpy wave drew the first matrix and rand()
