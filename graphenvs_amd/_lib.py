@@ -51,9 +51,10 @@ BUFFER_FIELDS = [
     "node_bits", "target_bits", "counters", "seed", "episode", "heuristic", "mt_state", "aux_bits",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
     "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
-    "node_aux", "range_bits", "cover_bits", "actions_out",
+    "node_aux", "range_bits", "cover_bits", "actions_out", "stream_state",
 ]
 SEED_DEPTH = 3  # GE_SEED_DEPTH
+STREAM_WORDS = 640  # GE_STREAM_WORDS
 
 
 class GeBuffers(C.Structure):
@@ -63,7 +64,7 @@ class GeBuffers(C.Structure):
 # every symbol include/graphenvs.h declares
 SYMBOLS = [
     "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_ragged_table_bytes", "ge_create_ragged", "ge_reset", "ge_step", "ge_step_only",
-    "ge_reset_pending", "ge_inject_state", "ge_mark_restored", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
+    "ge_reset_pending", "ge_reset_continue", "ge_inject_state", "ge_mark_restored", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
     "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash",
 ]
 
@@ -148,6 +149,8 @@ def bind(lib):
     lib.ge_inject_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.ge_mark_restored.restype = C.c_int
     lib.ge_mark_restored.argtypes = [vp]
+    lib.ge_reset_continue.restype = C.c_int
+    lib.ge_reset_continue.argtypes = [vp, vp]
     lib.ge_vectorize.restype = C.c_int
     lib.ge_vectorize.argtypes = [vp, vp, vp]
     lib.ge_sample_actions.restype = C.c_int
@@ -169,7 +172,7 @@ def bind(lib):
 _lib = None
 
 
-ABI_VERSION = 2  # GE_ABI_VERSION of include/graphenvs.h this host was written against
+ABI_VERSION = 3  # GE_ABI_VERSION of include/graphenvs.h this host was written against
 
 
 def load():

@@ -30,6 +30,7 @@ struct ge_engine {
   int feat64_pre_off, gen_pre_off;
   bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
   bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
+  bool streams;   // stream_state holds the streams a regeneration left behind (ge_reset; a restored snapshot)
 };
 
 static thread_local char g_err[256] = "";
@@ -241,7 +242,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   ge_engine *e = new (std::nothrow) ge_engine();
   if (!e) return fail(GE_E_BADARG, "out of host memory");
   e->P = P; e->cfg = *cfg; e->have_events = false;
-  e->loaded = false; e->seeded = false;
+  e->loaded = false; e->seeded = false; e->streams = false;
   e->n_classes = 0; memset(&e->R, 0, sizeof(e->R));
   return finish_create(e, out);
 }
@@ -286,7 +287,7 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
   e->P.buf = bufs[0];
   e->P.env_index_base = cfgs[0].env_index_base;
   e->cfg = cfgs[0]; e->cfg.num_envs = (int32_t)total;
-  e->have_events = false; e->loaded = false; e->seeded = false;
+  e->have_events = false; e->loaded = false; e->seeded = false; e->streams = false;
   e->n_classes = n_classes;
   if (hipMemcpy(class_table, e->classes.data(), sizeof(GeParams) * (size_t)n_classes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(slot_class, cls_of.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice) != hipSuccess ||
@@ -371,13 +372,20 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
   if (mode == GE_RESET_ALL) rc = launch_seed(e, seeds, 0, stream);
   else if (mode == GE_RESET_INJECT && inj.seeds) rc = launch_seed(e, inj.seeds, 1, stream);  // the injected episode needs no states of its own
   if (rc != GE_OK) return rc;
+  if (mode == GE_RESET_CONT) {
+    int64_t g = ((int64_t)e->P.B + GE_WAVE - 1) / GE_WAVE; if (g > 8192) g = 8192;
+    GE_LAUNCH(ge_k_seed_next, (int)g, 2 * GE_WAVE, GE_SEED_LDS_BYTES, stream, e->P);
+    rc = check_launch("seed kernel (next ring entry)");
+    if (rc != GE_OK) return rc;
+  }
   int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid + e->nseed : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
   if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
   else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
   rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;
-  if (mode != GE_RESET_INJECT) rc = launch_features(e, mode, stream);
+  if (mode != GE_RESET_INJECT) rc = launch_features(e, mode == GE_RESET_CONT ? (int)GE_RESET_ALL : mode, stream);
   if (rc == GE_OK && (mode == GE_RESET_ALL || inj.seeds)) e->seeded = true;
+  if (rc == GE_OK && mode == GE_RESET_ALL && e->P.buf.stream_state) e->streams = true;
   return rc;
 }
 
@@ -395,6 +403,17 @@ extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
   rc = launch_reset(e, seeds, GE_RESET_ALL, none, stream);
   if (rc == GE_OK) e->loaded = true;
   return rc;
+}
+
+extern "C" int ge_reset_continue(ge_engine *e, void *stream) {
+  if (!e) return fail(GE_E_BADARG, "null argument");
+  if (e->n_classes > 0) return fail(GE_E_UNSUPPORTED, "ge_reset_continue is not built for the multi-class engine");
+  if (!e->P.buf.stream_state) return fail(GE_E_STATE, "ge_reset_continue needs ge_buffers.stream_state (the streams every reset leaves behind)");
+  if (!e->loaded || !e->seeded || !e->streams) return fail(GE_E_STATE, "ge_reset_continue before ge_reset: there is no stream to continue");
+  GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int rc = clear_queue(e, stream);
+  if (rc != GE_OK) return rc;
+  return launch_reset(e, nullptr, GE_RESET_CONT, none, stream);
 }
 
 extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
@@ -501,7 +520,7 @@ extern "C" int ge_step(ge_engine *e, const int64_t *actions, void *stream) {
 // episode and a seeded generator ring.
 extern "C" int ge_mark_restored(ge_engine *e) {
   if (!e) return GE_E_BADARG;
-  e->loaded = true; e->seeded = true;
+  e->loaded = true; e->seeded = true; e->streams = e->P.buf.stream_state != nullptr;
   return GE_OK;
 }
 

@@ -103,6 +103,14 @@ GE_DEV void ge_mt_load(uint32_t *mt, const uint32_t *src, int lane) {
   ge_wave_sync();
 }
 
+// the reverse: a stream as a regeneration left it (state words, then the read position) to ge_buffers.stream_state
+GE_DEV void ge_mt_save(uint32_t *dst, const uint32_t *mt, int pos, int lane) {
+  ge_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 10; k++) { int i = lane + 64 * k; if (i < GE_MT_N) dst[i] = mt[i]; }
+  if (lane == 0) dst[GE_MT_N] = (uint32_t)pos;
+}
+
 GE_DEV int ge_wave_incl_scan(int x, int lane) {
   for (int off = 1; off < GE_WAVE; off <<= 1) {
     int t = ge_shfl_i32(x, lane >= off ? lane - off : 0);
@@ -225,7 +233,7 @@ GE_DEV int ge_sorted_pos_p(const GeParams &P, const GeRctx &c, int u, int v) {
   return P.complete ? c.rowptr[u] + v - (v > u ? 1 : 0) : ge_sorted_pos(c, P.W, u, v);
 }
 
-enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2 };
+enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2, GE_RESET_CONT = 3 };  // CONT: every slot, from the saved streams (reset(seed=None))
 
 struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; const uint32_t *seeds; };
 #ifndef GE_GNM_ROUND_CAP
@@ -845,16 +853,19 @@ GE_DEV void ge_np_multicast_tail(const GeParams &P, const GeRctx &c, uint32_t *m
 // The numpy wave (second wave of the reset workgroup): everything the numpy stream produces that does not
 // depend on the topology runs beside the python-stream graph sampling of the first wave.
 template <int ENV>
-GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt_src, int lane, int env) {
+GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt_src, int lane, int env, int np0, uint32_t *save) {
   constexpr int t = ENV;  // compile-time: every env type gets its own reset kernel, so none pays for the others' registers
   const int n = P.n;
   (void)env;  // only the diagnostic stamps name the slot
-  if (t == GE_DENSEST_SUBGRAPH) return;  // seeds numpy but never draws (densest_subgraph.py:52-98)
+  if (t == GE_DENSEST_SUBGRAPH) {  // seeds numpy but never draws (densest_subgraph.py:52-98): the saved stream is the one it was given
+    if (save && save != mt_src) { for (int i = lane; i < GE_MT_N; i += GE_WAVE) save[i] = mt_src[i]; if (lane == 0) save[GE_MT_N] = (uint32_t)np0; }
+    return;
+  }
   GE_STAMP(20);
-  ge_mt_load(c.mt2, mt_src, lane);  // pre-seeded
+  ge_mt_load(c.mt2, mt_src, lane);  // pre-seeded (or, continuing, as the previous regeneration left it)
   GE_STAMP(21);
   if (!P.np_early) return;               // big delay matrix: the first wave draws after the topology is known
-  int nppos = GE_MT_N;
+  int nppos = np0;
   const bool path_like = (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING || t == GE_DISTRIBUTION_CENTER ||
                           t == GE_PERISHABLE_DELIVERY);
   if (P.spatial) {  // tsp.py:81-83: x, y = np.random.rand() * 10 per node; rand() = two 32-bit draws, no rejection
@@ -886,11 +897,12 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt
     const uint32_t ra = ge_np_next(c.mt2, nppos, lane), rb = ge_np_next(c.mt2, nppos, lane);
     if (lane == 0) { *(double *)c.misc = ((double)(int32_t)(ra >> 5) * 67108864.0 + (double)(int32_t)(rb >> 6)) / 9007199254740992.0; c.misc[2] = nppos; }
     ge_wave_sync();
-    return;
+    return;  // the first wave goes on with this stream (and saves it)
   }
   if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
   else if (path_like) ge_np_terminals(P, c, c.mt2, nppos, lane, n, P.T);
   GE_STAMP(23);
+  if (save) ge_mt_save(save, c.mt2, nppos, lane);
 }
 
 // DistributionCenter, n <= 64: nodes within `cutoff` of `s` (float64 sums taken from s outwards), by a label-correcting search
@@ -935,17 +947,25 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   // seed / episode alone (the episodes that follow continue the earlier sequence).  In queue mode seed[] / episode[] still hold
   // the OLD episode while this kernel runs -- its seeding workgroups read them too -- and the feature kernel, the last kernel
   // of a regeneration, advances them (ge_advance_episode).
+  // GE_RESET_CONT (reset(seed=None), shortest_path.py:49-52): like a queued regeneration the slot moves to its next episode, but the
+  // two streams are the ones its previous regeneration left in stream_state, not freshly seeded ones.
   const bool restart = (mode == GE_RESET_ALL) || (mode == GE_RESET_INJECT && inj.seeds);
-  const int64_t episode = restart ? 0 : P.buf.episode[env] + (mode == GE_RESET_QUEUE ? 1 : 0);
-  const uint32_t seed = restart ? (mode == GE_RESET_ALL ? seeds[env] : inj.seeds[env]) : P.buf.seed[env] + (mode == GE_RESET_QUEUE ? (uint32_t)P.seed_stride : 0u);
+  const bool next = (mode == GE_RESET_QUEUE || mode == GE_RESET_CONT);
+  const int64_t episode = restart ? 0 : P.buf.episode[env] + (next ? 1 : 0);
+  const uint32_t seed = restart ? (mode == GE_RESET_ALL ? seeds[env] : inj.seeds[env]) : P.buf.seed[env] + (next ? (uint32_t)P.seed_stride : 0u);
   const int ring = (int)(episode % GE_SEED_DEPTH);
+  // where the streams are left (recomputed at each use: nothing about it stays live through the kernel)
+  auto keep_at = [&](int which) -> uint32_t * { return P.buf.stream_state ? P.buf.stream_state + ((int64_t)env * 2 + which) * GE_STREAM_WORDS : nullptr; };
+  // a stream's read position when this regeneration starts: a freshly seeded state is twisted before its first draw
+  auto pos0 = [&](int which) -> int { return mode == GE_RESET_CONT ? (int)keep_at(which)[GE_MT_N] : GE_MT_N; };
   const uint32_t *mt_src = P.buf.mt_state + ((int64_t)env * GE_SEED_DEPTH + ring) * 2 * GE_MT_N;
+  if (mode == GE_RESET_CONT) mt_src = keep_at(0);
   int src = 0, dest = -1;
   int ppd_pk[5] = {-1, -1, -1, -1, -1}, ppd_dp[5] = {-1, -1, -1, -1, -1};  // perishable_product_delivery.py:72-73
   bool gen_failed = false;
   double ppd_dt = 0.0;
   if (wv == 1) {
-    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, mt_src + GE_MT_N, lane, env); ge_sync(); }
+    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, mode == GE_RESET_CONT ? keep_at(1) : mt_src + GE_MT_N, lane, env, pos0(1), keep_at(1)); ge_sync(); }
     ge_sync();
     return;
   }
@@ -955,7 +975,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     // ---------------------------------------------------------------- topology (python stream)
     ge_mt_load(c.mt, mt_src, lane);  // pre-seeded (ge_k_seed)
     GE_STAMP(1);
-    int pypos = GE_MT_N;
+    int pypos = pos0(0);
     int ppd_attempt = 0, ppd_pos = 0;  // PerishableProductDelivery: the numpy stream is continued by this wave after the join
     bool failed = false;               // the G(n, m) loop hit its round cap (wave-uniform)
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
@@ -1083,7 +1103,11 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
           }
       }
       ge_wave_sync();
-      if (t == GE_PERISHABLE_DELIVERY) { if (ppd_attempt == 0) ge_sync(); for (int i = 0; i < P.n_dests; i++) { ppd_pk[i] = i; ppd_dp[i] = P.n_dests + i; } }
+      if (t == GE_PERISHABLE_DELIVERY) { if (ppd_attempt == 0) { ge_sync(); ppd_pos = c.misc[2]; } for (int i = 0; i < P.n_dests; i++) { ppd_pk[i] = i; ppd_dp[i] = P.n_dests + i; } }
+    }
+    if (P.buf.stream_state) {
+      ge_mt_save(keep_at(0), c.mt, pypos, lane);
+      if (t == GE_PERISHABLE_DELIVERY) ge_mt_save(keep_at(1), c.mt2, ppd_pos, lane);  // this wave took the numpy stream over
     }
   } else {
     // ---------------------------------------------------------------- injected topology
@@ -1200,11 +1224,12 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     } else if (t == GE_MAX_INDEPENDENT_SET) {
       for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = P.weighted ? (int)((const uint8_t *)c.wm)[v] : 10;
     } else if (P.weighted && matrix_w) {  // n too large for the dense matrix: draw now, codes land by rank
-      int nppos = GE_MT_N;
+      int nppos = pos0(1);
       ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 2);
       if (t == GE_DISTRIBUTION_CENTER) ge_np_draws(P, c, c.mt2, nppos, n, lane, 3);
       if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
       else ge_np_terminals(P, c, c.mt2, nppos, lane, n, P.T);
+      if (P.buf.stream_state) ge_mt_save(keep_at(1), c.mt2, nppos, lane);
     }
     ge_wave_sync();
     for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
@@ -1611,6 +1636,22 @@ GE_KERNEL ge_k_seed(GeParams P, const uint32_t *seeds, int jlo) {
       const int j = jlo + (int)(g / P.B), env = (int)(g % P.B);
       sb = (uint32_t)env * GE_SEED_DEPTH + (uint32_t)j;
       seed = seeds[env] + (uint32_t)j * (uint32_t)P.seed_stride;
+    }
+    ge_seed_group(P, ge_dyn_smem(), sb, seed, tid);
+  }
+}
+
+// ge_reset_continue: every slot leaves its episode e without the queued regeneration whose seeding workgroups would have
+// refilled ring entry e mod GE_SEED_DEPTH with the states of episode e + GE_SEED_DEPTH; this launch (in front of the graph kernel,
+// while seed[] / episode[] still name episode e) does it for the whole batch.
+GE_KERNEL ge_k_seed_next(GeParams P) {
+  const int tid = ge_tid();
+  for (int64_t g0 = (int64_t)ge_bid() * GE_WAVE; g0 < P.B; g0 += (int64_t)ge_gdim() * GE_WAVE) {
+    const int64_t g = g0 + (ge_tid_fresh() & (GE_WAVE - 1));
+    uint32_t sb = 0xffffffffu, seed = 0u;
+    if (g < P.B) {
+      sb = (uint32_t)g * GE_SEED_DEPTH + (uint32_t)(P.buf.episode[g] % GE_SEED_DEPTH);
+      seed = P.buf.seed[g] + (uint32_t)GE_SEED_DEPTH * (uint32_t)P.seed_stride;
     }
     ge_seed_group(P, ge_dyn_smem(), sb, seed, tid);
   }

@@ -21,7 +21,7 @@ class GraphEnv:
     def __init__(self, env_id, n_nodes, n_edges=-1, device="cuda", _library=None, **kwargs):
         self.env_id = env_id
         self._v = VectorGraphEnv(env_id, 1, n_nodes, n_edges, device=device, autoreset=False, obs_mode="flat",
-                                 _library=_library, **kwargs)
+                                 continue_streams=True, _library=_library, **kwargs)
         self.n_nodes, self.n_edges = self._v.n, self._v.m
         self.action_space = self._v.single_action_space
         self.observation_space = self._v.single_observation_space
@@ -31,8 +31,8 @@ class GraphEnv:
         return t.detach().cpu().numpy()
 
     def reset(self, seed=None, options=None):
-        """reset(seed=s) reproduces the reference's reset(seed=s).  seed=None moves to the slot's next
-        episode seed (the reference would continue the process-global streams instead)."""
+        """reset(seed=s) reproduces the reference's reset(seed=s); reset() after it continues the `random` / `np.random` streams
+        where that reset left them, like the reference (shortest_path.py:49-52).  A first reset() without a seed uses seed 0."""
         obs, info = self._v.reset(seed=None if seed is None else [int(seed)])
         self._last_cost = np.float64(0.0)
         self._edges_taken, self._nodes_taken = [], set()  # longest_path.py:115, perishable_product_delivery.py:161, densest_subgraph.py:95

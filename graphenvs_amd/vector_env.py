@@ -139,7 +139,7 @@ class VectorGraphEnv(_VectorBase):
 
     def __init__(self, env_id, num_envs, n_nodes, n_edges=-1, device="cuda", autoreset=True, obs_mode="pyg",
                  env_index_base=0, seed_stride=None, strict=False, _library=None, _views=None, node_id_base=0,
-                 edge_row_stride=0, record_actions=False, copy_outputs=False, _defer_create=False, **kwargs):
+                 edge_row_stride=0, record_actions=False, copy_outputs=False, continue_streams=False, _defer_create=False, **kwargs):
         self.env_id = env_id
         self.kwargs = normalize_kwargs(env_id, n_nodes, n_edges, **kwargs)
         self.num_envs = int(num_envs)
@@ -147,6 +147,10 @@ class VectorGraphEnv(_VectorBase):
         self.obs_mode = obs_mode
         self.strict = strict
         self.copy_outputs = bool(copy_outputs)
+        # reset(seed=None) like the reference (shortest_path.py:49-52): every slot draws its next graph from where its previous
+        # reset left its `random` / `np.random` streams (5 KiB of saved generator state per slot, written by every reset).
+        # Off: reset(seed=None) moves every slot to its next episode seed (seed + seed_stride), like an autoreset does.
+        self.continue_streams = bool(continue_streams)
         # return_graph_obs (shortest_path.py:94-95 and siblings): info['graph_obs'] = per-slot (nodes, edges, edge_links) views
         self.return_graph_obs = bool(self.kwargs.get("return_graph_obs", False))
         # True / "same_step": a finished slot is regenerated inside the same step(); "next_step" (gymnasium's default mode): the
@@ -226,6 +230,7 @@ class VectorGraphEnv(_VectorBase):
         # where the fused policy+step launches record the actions they drew (record_actions=True); off by default: 8 bytes
         # per slot and step less to write
         t["actions_out"] = z((B,), torch.int64) if record_actions else None
+        t["stream_state"] = z((B, 2, _lib.STREAM_WORDS), torch.int32) if self.continue_streams else None
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 if t[k] is None:
@@ -246,6 +251,7 @@ class VectorGraphEnv(_VectorBase):
         self._actions_scratch = z((B,), torch.int64)
         self._flat = None
         self._was_reset = False
+        self._streams = False  # stream_state holds the streams of a reset (continue_streams)
         self.single_action_space = _Space(n=(self.m if edge_env else n), mask_size=A)  # steiner_tree.py:43, multicast_routing.py:67
         self.single_observation_space = _Space(shape=(self.obs_len,), dtype=np.float32)
         if _GYM is not None and hasattr(_GYM, "spaces"):  # the reference's spaces (shortest_path.py:40-42), and their batched forms
@@ -342,11 +348,16 @@ class VectorGraphEnv(_VectorBase):
 
     def reset(self, seed=None, options=None):
         """reset(seed=s): slot i (global index g) runs the reference's reset(seed=(s+g) mod 2^32); a
-        sequence/tensor gives every slot its own seed."""
+        sequence/tensor gives every slot its own seed.  reset() without a seed: see ``continue_streams``."""
+        if seed is None and self._streams:
+            _lib.check(self._L, self._L.ge_reset_continue(self._h, self._stream()), "ge_reset_continue")
+            out = (self._obs(), self._info(False))
+            return self._copied(out) if self.copy_outputs else out
         seeds = self._seed_tensor(seed)
         self._seeds_keepalive = seeds
         _lib.check(self._L, self._L.ge_reset(self._h, seeds.data_ptr(), self._stream()), "ge_reset")
         self._was_reset = True
+        self._streams = self.continue_streams
         out = (self._obs(), self._info(False))
         return self._copied(out) if self.copy_outputs else out
 
@@ -458,6 +469,7 @@ class VectorGraphEnv(_VectorBase):
             dict.__getitem__(self.t, k).copy_(v)
         self._L.ge_mark_restored(self._h)
         self._was_reset = True
+        self._streams = self.continue_streams and "stream_state" in sd
         self._quiesce()
 
     def check_device_errors(self):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 2
+#define GE_ABI_VERSION 3
 
 /* env ids of graph_envs/__init__.py:9-56 that are on the hot path */
 enum {
@@ -53,6 +53,7 @@ enum {
                                                3 regenerated in this ge_step (next-step mode), 4 generation failed (see work_count[1]) */
 #define GE_REC_AUX_SHIFT   24               /* bits 24-31: ShortestPath / LongestPath with n <= 64: the destination node */
 #define GE_REC_TSTEP_SHIFT 32               /* bits 32-63: transitions executed by the slot since the last ge_reset (mod 2^32) */
+#define GE_STREAM_WORDS 640                 /* one saved generator stream in ge_buffers.stream_state: 624 state words, the read position, padding */
 #define GE_SEED_DEPTH 3                     /* ring of generator states per slot: episode e lives in entry e mod 3; while a slot runs episode e the
                                                entries of e+1 and e+2 are valid and the entry of e is being refilled with e+3 */
 
@@ -154,6 +155,9 @@ typedef struct {
   uint64_t *cover_bits; /* [B, W] DistributionCenter: covered nodes; else NULL */
   int64_t *actions_out; /* [B]  optional (may be NULL): where the fused policy+step launches of ge_random_rollout / ge_timed_*
                                  record the actions they drew; NULL = not recorded (8 bytes per slot and step less to write) */
+  uint32_t *stream_state; /* [B, 2, GE_STREAM_WORDS] optional (may be NULL): the python and the numpy MT19937 stream of every slot as its
+                                 last regeneration LEFT them (624 state words, then the read position), written by every reset
+                                 when present -- what ge_reset_continue (reset(seed=None), shortest_path.py:49-52) resumes from */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;
@@ -196,6 +200,12 @@ int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, int32_t n_cl
  * Runs graph sampling, weights (a8), terminals (a9), structural features (a6),
  * baselines (a16), first mask; fills the observation slabs. */
 int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream);
+
+/* env.reset() WITHOUT a seed for every slot (shortest_path.py:49-52: the process-global `random` / `np.random` streams are
+ * not re-seeded, the new graph is drawn from where the previous reset left them).  Needs ge_buffers.stream_state and an
+ * earlier ge_reset on this engine (GE_E_STATE otherwise).  Every slot moves to its next episode index; seed[] advances by
+ * seed_stride so that the autoreset episodes that follow are the ones a fresh ge_reset would have been followed by. */
+int ge_reset_continue(ge_engine *e, void *stream);
 
 /* env.step(a) for every slot (shortest_path.py:111-141 and siblings).  actions [B] int64 on
  * device.  Writes reward/terminated/invalid/solved/final_* and the next mask; with autoreset

@@ -46,7 +46,7 @@ def unpack_mask(packed, A):
 
 
 def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True, feature_slice=None,
-                feature_ulps=0):
+                feature_ulps=0, unseeded_reset=True):
     """Replay every seed/policy of a fixture on env = make_env(env_id, **kwargs).
 
     feature_slice/feature_ulps: columns of x holding float64-derived structural features may be
@@ -121,6 +121,14 @@ def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True
                     elif kind == "mis":       # two independent sets of the same graph
                         assert h == int(h) and 1 <= h <= n and 1 <= ref_h <= n, what
                         stats["mis_ours_ge_ref"] = stats.get("mis_ours_ge_ref", 0) + int(h >= ref_h)
+            if unseeded_reset and pol + "_reset2_obs_sha" in case:
+                # reset() without a seed continues the `random` / `np.random` streams where reset(seed=) left them (shortest_path.py:49-52)
+                obs2, info2 = env.reset()
+                tag = f"{meta['case']} seed {seed} {pol}: reset() after the episode"
+                assert np.array_equal(np.asarray(info2["mask"]), case[pol + "_reset2_mask"][si]), tag + ": mask"
+                if feature_ulps == 0:
+                    assert sha64(np.asarray(obs2)) == case[pol + "_reset2_obs_sha"][si], tag + ": obs hash"
+                stats["unseeded_resets"] = stats.get("unseeded_resets", 0) + 1
     return stats
 
 

@@ -97,3 +97,50 @@ def check_graph_obs(ge, device, lib):
     from graphenvs_amd import utils
     assert np.array_equal(utils.vectorize_graph(inf["graph_obs"]), o)
     env.close(); single.close()
+
+
+def check_continue_streams(ge, oracle, device, lib):
+    """reset() without a seed in a batch with autoreset (continue_streams=True): every slot draws its next graph from where its LAST
+    regeneration -- whichever seeded episode that was -- left the two streams (shortest_path.py:49-52), and the autoreset episodes
+    after it are seeded as if that reset had been one (the ring entry it skipped is refilled)."""
+    B, n, m, stride = 6, 6, 9, 50
+    kw = dict(n_nodes=n, n_edges=m)
+    for env_id, extra in (("ShortestPath-v0", {}), ("SteinerTree-v0", dict(n_dests=2))):
+        refs = [oracle.OracleEnv(env_id, **kw, **extra) for _ in range(B)]
+        seeds = [7 + i for i in range(B)]
+        env = ge.VectorGraphEnv(env_id, B, obs_mode="flat", autoreset=True, seed_stride=stride, continue_streams=True,
+                                **_extra(device, lib), **kw, **extra)
+        with pytest.raises(RuntimeError, match="ge_reset"):  # nothing to continue yet: the C ABI refuses
+            env._streams = True; env.reset()
+        env._streams = False
+        env.reset(seed=seeds)
+        for r, sd in zip(refs, seeds):
+            r.reset(seed=sd)
+        resets = 0
+
+        def roll(K):
+            nonlocal resets
+            for k in range(K):
+                a = env.sample_random_actions(policy_seed=3).clone()
+                obs, rew, term, _, info = env.step(a)
+                a, rew, term = a.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+                for i, r in enumerate(refs):
+                    _, rr, dd, _, _ = r.step(int(a[i]))
+                    assert rr == float(rew[i]) and dd == bool(term[i]), (env_id, k, i)
+                    if dd:
+                        seeds[i] += stride; r.reset(seed=seeds[i]); resets += 1
+                assert np.array_equal(env.flat_obs().cpu().numpy(), np.stack([r.obs() for r in refs])), (env_id, k)
+                assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), (env_id, k)
+
+        roll(12)
+        for rnd in range(2):
+            obs, info = env.reset()  # continues every slot's streams
+            for i, r in enumerate(refs):
+                r.reset(); seeds[i] += stride  # the bookkeeping moves on one episode
+            assert np.array_equal(obs.cpu().numpy(), np.stack([r.obs() for r in refs])), (env_id, rnd)
+            assert np.array_equal(info["mask"].cpu().numpy(), np.stack([r.mask() for r in refs])), (env_id, rnd)
+            roll(25)  # more than GE_SEED_DEPTH autoresets per slot: round the ring, past the refilled entry
+        assert resets > 4 * B
+        assert env.t["seed"].cpu().numpy().view(np.uint32).tolist() == seeds
+        env.check_device_errors()
+        env.close()

@@ -159,5 +159,10 @@ def test_emulated_state_dict_moves_between_engines(emu):
     hc.check_state_dict_move(ge, "cpu", emu)
 
 
+def test_emulated_unseeded_reset_continues_the_streams_of_every_slot(emu):
+    import oracle
+    hc.check_continue_streams(ge, oracle, "cpu", emu)
+
+
 def test_emulated_return_graph_obs_and_copy_outputs(emu):
     hc.check_graph_obs(ge, "cpu", emu)

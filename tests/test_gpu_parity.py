@@ -539,6 +539,12 @@ def test_state_dict_moves_between_engines():
     hc.check_state_dict_move(_ge(), "cuda", None)
 
 
+def test_unseeded_reset_continues_the_streams_of_every_slot():
+    import host_checks as hc
+    import oracle
+    hc.check_continue_streams(_ge(), oracle, "cuda", None)
+
+
 def test_return_graph_obs_and_copy_outputs():
     import host_checks as hc
     hc.check_graph_obs(_ge(), "cuda", None)
