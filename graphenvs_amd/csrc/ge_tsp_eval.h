@@ -1,0 +1,89 @@
+// TSP-v0 baseline (is_eval_env only): info['heuristic_solution'] = length of a Christofides tour (tsp.py:114-117 calls
+// nx.approximation.traveling_salesman_problem: all-pairs Dijkstra, Christofides on the metric closure).  Two launches behind the
+// graph kernel, on the slabs it wrote, outside the reset kernels so that the training path (no baseline) carries none of this:
+//   ge_k_tsp_closure  one wave per regenerated slot, one LANE per Dijkstra source: integer distances (weight codes = tenths;
+//                     spatial: Euclidean lengths in 1/65536) into the slot's scratch block, D[n][n];
+//   ge_k_tsp_tour     one LANE per regenerated slot runs ge_christofides.h on that block (spanning tree, exact minimum-weight
+//                     perfect matching of the odd nodes by the blossom algorithm, Eulerian circuit, shortcutting) and replaces the
+//                     double-tree value 2 x MST the graph kernel left in heuristic[].
+// This is an evaluation-time path (the reference spends seconds per reset in networkx here): lanes run unrelated sequential
+// programs, nothing is tuned beyond keeping every slot of a launch busy side by side.
+#pragma once
+#include "ge_params.h"
+#include "ge_reset.h"
+
+#ifdef GE_EMU
+#define GE_CH_FN static inline
+#else
+#define GE_CH_FN static __device__
+#define GE_CH_HD static __host__ __device__ inline
+#endif
+#include "ge_christofides.h"
+
+#define GE_TSP_EVAL_THREADS 64
+
+GE_DEV int32_t ge_tsp_units(const GeParams &P, double w) { return (int32_t)llrint(w * 65536.0); }
+
+// items of the launch: every slot (full reset) or the queued ones; `pre` (LDS) holds the queue prefix in queue mode
+GE_DEV int ge_tsp_count(const GeParams &P, int *pre, int mode) {
+  if (mode != GE_RESET_QUEUE) return P.B;
+  if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
+  ge_sync();
+  return pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
+}
+
+GE_KERNEL ge_k_tsp_closure(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes, int pre_off) {
+  uint64_t *done_all = (uint64_t *)ge_dyn_smem();  // [64 lanes][W] settled sets
+  int *pre = (int *)(ge_dyn_smem() + pre_off);
+  const int count = ge_tsp_count(P, pre, mode);
+  const int n = P.n, W = P.W, lane = ge_tid();
+  uint64_t *done = done_all + lane * W;
+  const ge_buffers &G = P.buf;
+  for (int q = ge_bid(); q < count; q += ge_gdim()) {
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    int32_t *D = (int32_t *)(scratch + (uint64_t)env * slot_bytes);
+    const int32_t *rp = G.row_ptr + (int64_t)env * (n + 1);
+    const int64_t ebase = (int64_t)env * P.E;
+    for (int s = lane; s < n; s += GE_WAVE) {  // array Dijkstra from s: the row D[s][*] is the tentative-distance array
+      int32_t *row = D + (int64_t)s * n;
+      for (int v = 0; v < n; v++) row[v] = INT32_MAX;
+      for (int w = 0; w < W; w++) done[w] = 0ull;
+      row[s] = 0;
+      for (int it = 0; it < n; it++) {
+        int v = -1; int32_t best = INT32_MAX;
+        for (int u = 0; u < n; u++) { const int32_t d = row[u]; if (d < best && !((done[u >> 6] >> (u & 63)) & 1ull)) { best = d; v = u; } }
+        if (v < 0) break;
+        done[v >> 6] |= 1ull << (v & 63);
+        if (P.spatial) {  // sw64: float64 lengths in ascending-neighbour order
+          int j = rp[v];
+          for (int w = 0; w < W; w++)
+            for (uint64_t bits = G.adj_bits[((int64_t)env * n + v) * W + w]; bits; bits &= bits - 1, j++) {
+              const int u = w * 64 + ge_ctz64(bits); const int32_t d = best + ge_tsp_units(P, G.sw64[ebase + j]);
+              if (d < row[u]) row[u] = d;
+            }
+        } else {
+          for (int k = rp[v]; k < rp[v + 1]; k++) {
+            const uint16_t cw = G.colw[ebase + k]; const int u = cw >> 4; const int32_t d = best + (int32_t)(cw & 15);
+            if (d < row[u]) row[u] = d;
+          }
+        }
+      }
+    }
+  }
+}
+
+GE_KERNEL ge_k_tsp_tour(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
+  int *pre = (int *)ge_dyn_smem();
+  const int count = ge_tsp_count(P, pre, mode);
+  const int n = P.n;
+  for (int q = ge_bid() * GE_TSP_EVAL_THREADS + ge_tid(); q < count; q += ge_gdim() * GE_TSP_EVAL_THREADS) {
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    uint8_t *blk = scratch + (uint64_t)env * slot_bytes;
+    ge_ch c;
+    c.err = 0;
+    ge_ch_carve(&c, blk + ge_ch_align((uint64_t)n * (uint64_t)n * 4u), n);
+    c.D = (const int32_t *)blk;
+    const int64_t tot = ge_christofides_tour(&c);
+    if (tot >= 0) P.buf.heuristic[env] = (double)tot / (P.spatial ? 65536.0 : 10.0);  // else: the double-tree walk stays
+  }
+}

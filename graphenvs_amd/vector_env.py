@@ -231,6 +231,7 @@ class VectorGraphEnv(_VectorBase):
         # per slot and step less to write
         t["actions_out"] = z((B,), torch.int64) if record_actions else None
         t["stream_state"] = z((B, 2, _lib.STREAM_WORDS), torch.int32) if self.continue_streams else None
+        t["eval_scratch"] = z((lay.eval_scratch_bytes,), torch.uint8) if lay.eval_scratch_bytes else None  # TSP is_eval_env: Christofides work space
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 if t[k] is None:
@@ -461,7 +462,7 @@ class VectorGraphEnv(_VectorBase):
     def state_dict(self):
         """Snapshot of every engine slab: the whole state of the batch, generator states included."""
         self._quiesce()
-        return {k: v.clone() for k, v in dict.items(self.t) if v is not None}
+        return {k: v.clone() for k, v in dict.items(self.t) if v is not None and k != "eval_scratch"}  # work space, not state
 
     def load_state_dict(self, sd):
         self._quiesce()

@@ -428,6 +428,76 @@ static double mst_total(oge_env *e) {
   return s;
 }
 
+/* ------------------------------------------------------------------ TSP baseline: a Christofides tour */
+/* tsp.py:114-117 calls networkx's Christofides on the metric closure; its tie-breaks (Kruskal order, blossom matching, circuit
+ * order) depend on dict / set iteration orders, so the checker -- like the engine, from the same text
+ * (graphenvs_amd/csrc/ge_christofides.h: an own heuristic has no reference semantics to restate twice) -- builds A Christofides
+ * tour with its own deterministic choices.  tests/ check the pieces against exhaustive search.  Integer lengths: weight codes in
+ * tenths, or Euclidean lengths in 1/65536 (spatial). */
+#include "../graphenvs_amd/csrc/ge_christofides.h"
+
+static void closure_row(const oge_env *e, int s, int spatial, int32_t *row, uint8_t *done) {
+  int n = e->n;
+  for (int v = 0; v < n; v++) { row[v] = INT32_MAX; done[v] = 0; }
+  row[s] = 0;
+  for (;;) {
+    int v = -1; int32_t best = INT32_MAX;
+    for (int u = 0; u < n; u++) if (!done[u] && row[u] < best) { best = row[u]; v = u; }
+    if (v < 0) break;
+    done[v] = 1;
+    for (int k = e->row_ptr[v]; k < e->row_ptr[v + 1]; k++) {
+      int32_t w = spatial ? (int32_t)llrint(e->w64[k] * 65536.0) : (int32_t)llrint(e->w64[k] * 10.0);
+      if (row[v] + w < row[e->col[k]]) row[e->col[k]] = row[v] + w;
+    }
+  }
+}
+
+static int64_t christofides_units(int n, uint8_t *blk) {
+  ge_ch c;
+  memset(&c, 0, sizeof c);
+  ge_ch_carve(&c, blk + ge_ch_align((uint64_t)n * n * 4u), n);
+  c.D = (const int32_t *)blk;
+  return ge_christofides_tour(&c);
+}
+
+static double christofides_baseline(oge_env *e, double fallback) {
+  int n = e->n, spatial = e->cfg.spatial;
+  uint8_t *blk = (uint8_t *)malloc(ge_ch_slot_bytes(n));
+  for (int s = 0; s < n; s++) closure_row(e, s, spatial, (int32_t *)blk + (size_t)s * n, e->tmp8);
+  int64_t tot = christofides_units(n, blk);
+  free(blk);
+  return tot < 0 ? fallback : (double)tot / (spatial ? 65536.0 : 10.0);
+}
+
+/* test hooks: the tour length on a given closure matrix D [n*n]; the minimum weight of a perfect matching of dist [k*k]
+ * (k even), with the partner of every vertex in match_out */
+int64_t oge_debug_christofides(int32_t n, const int32_t *D) {
+  uint8_t *blk = (uint8_t *)malloc(ge_ch_slot_bytes(n));
+  memcpy(blk, D, (size_t)n * n * 4u);
+  int64_t tot = christofides_units(n, blk);
+  free(blk);
+  return tot;
+}
+
+int64_t oge_debug_min_matching(int32_t k, const int32_t *dist, int32_t *match_out) {
+  uint8_t *blk = (uint8_t *)malloc(ge_ch_slot_bytes(k));
+  ge_ch c;
+  memset(&c, 0, sizeof c);
+  ge_ch_carve(&c, blk + ge_ch_align((uint64_t)k * k * 4u), k);
+  c.k = k;
+  int32_t dmax = 0;
+  for (int i = 0; i < k * k; i++) if (dist[i] > dmax) dmax = dist[i];
+  for (int a = 0; a <= k; a++) for (int b = 0; b <= k; b++) c.W[a * (k + 1) + b] = (a && b && a != b) ? dmax + 1 - dist[(a - 1) * k + (b - 1)] : 0;
+  ge_bl_solve(&c);
+  int64_t tot = 0;
+  for (int a = 1; a <= k; a++) {
+    match_out[a - 1] = c.err ? -1 : (int32_t)c.match[a] - 1;
+    if (!c.err && c.match[a] > a) tot += dist[(a - 1) * k + (c.match[a] - 1)];
+  }
+  free(blk);
+  return c.err ? -1 : tot;
+}
+
 /* ------------------------------------------------------------------ masks */
 /* BFS reach set from `from` inside alive nodes, optionally without `skip` */
 static int residual_reach(oge_env *e, int from, int skip, uint8_t *seen) {
@@ -872,8 +942,9 @@ int oge_reset(oge_env *e, int64_t seed) {
     if (e->cfg.parenting >= 2) { e->alive[0] = 0; e->n_alive--; }
     build_directed(e);
     if (e->cfg.spatial) for (int v = 0; v < n; v++) { e->x[v * F + 2] = (float)px[v]; e->x[v * F + 3] = (float)pyy[v]; }
-    /* own double-tree bound in place of Christofides: the closed walk around a minimum spanning tree, 2 * MST (bound-checked) */
-    if (e->cfg.is_eval_env) { double mst = mst_total(e); e->heuristic = mst + mst; }
+    /* a Christofides tour with own tie-breaks in place of networkx's (bound-checked); the double-tree walk 2 * MST only if
+       the matching scratch were ever too small */
+    if (e->cfg.is_eval_env) { double mst = mst_total(e); e->heuristic = christofides_baseline(e, mst + mst); }
     e->x[e->start * F + 1] = 1.f; e->head = e->start;
     for (int p = 0; p < e->E; p++) e->ef[p] = (float)e->w64[p];
     pr_weighted = 1;

@@ -96,6 +96,10 @@ int64_t oge_rollout(const oge_cfg *cfg, int64_t first_seed, int64_t seed_stride,
  * recomputed on the graph of the last reset; both return the heuristic value */
 double oge_debug_greedy_mis(oge_env *e, uint8_t *out_n);
 double oge_debug_steiner_tree(oge_env *e, uint8_t *out_nn);
+/* the TSP baseline's pieces: tour length (integer units) of the Christofides tour on a closure matrix D [n*n]; minimum weight
+ * of a perfect matching of dist [k*k] (k even) with every vertex's partner in match_out [k] */
+int64_t oge_debug_christofides(int32_t n, const int32_t *D);
+int64_t oge_debug_min_matching(int32_t k, const int32_t *dist, int32_t *match_out);
 
 /* iteration order of a CPython 3.10 set after adding the int pairs (u[i], v[i]) in order (multicast baseline sums a set) */
 int oge_pyset_order(const int32_t *u, const int32_t *v, int count, int32_t *out_u, int32_t *out_v);

@@ -38,7 +38,8 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (no GPU involved)."""
     src = os.path.join(_HERE, "ge_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ge_oracle.h"))):
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ge_oracle.h")),
+            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_christofides.h"))):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libge_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -82,6 +83,10 @@ def lib():
         L.oge_debug_greedy_mis.argtypes = [vp, vp]
         L.oge_debug_steiner_tree.restype = dbl
         L.oge_debug_steiner_tree.argtypes = [vp, vp]
+        L.oge_debug_christofides.restype = i64
+        L.oge_debug_christofides.argtypes = [i32, vp]
+        L.oge_debug_min_matching.restype = i64
+        L.oge_debug_min_matching.argtypes = [i32, vp, vp]
         L.oge_pyset_order.restype = C.c_int
         L.oge_pyset_order.argtypes = [vp, vp, C.c_int, vp, vp]
         L.oge_mt_py_seed.argtypes = [vp, C.c_uint32]
@@ -247,3 +252,16 @@ def pyset_order(pairs):
     ou, ov = np.zeros(len(pairs) + 1, dtype=np.int32), np.zeros(len(pairs) + 1, dtype=np.int32)
     k = lib().oge_pyset_order(u.ctypes.data, v.ctypes.data, len(pairs), ou.ctypes.data, ov.ctypes.data)
     return [(int(a), int(b)) for a, b in zip(ou[:k], ov[:k])]
+
+
+def christofides_units(D):
+    """tour length (integer units) of the checker's Christofides tour on the closure matrix D [n, n] int32"""
+    D = np.ascontiguousarray(D, dtype=np.int32)
+    return int(lib().oge_debug_christofides(D.shape[0], D.ctypes.data))
+
+
+def min_matching(dist):
+    """(minimum weight, partner of every vertex) of a perfect matching of the complete graph with lengths dist [k, k] int32"""
+    dist = np.ascontiguousarray(dist, dtype=np.int32)
+    out = np.zeros(dist.shape[0], dtype=np.int32)
+    return int(lib().oge_debug_min_matching(dist.shape[0], dist.ctypes.data, out.ctypes.data)), out

@@ -17,7 +17,7 @@ import graphenvs_amd as ge  # noqa: E402
 
 FAST = ["sp_n10_m20_eval", "sp_n5_m7", "sp_n33_m70", "sp_n64_m192_eval", "lp_n10_m20_p0", "lp_n10_m20_p1",
         "st_n10_m20_d1_eval", "st_n10_m20_d3_eval", "st_n10_m20_d9_eval", "st_n5_m10_d4", "tsp_n8_m28_p1",
-        "tsp_n10_m20_p1", "tsp_n12_m30_p1_unweighted", "mis_n6_m8", "mis_n5_m7_unweighted", "ds_n10_m20_p1",
+        "tsp_n10_m20_p1", "tsp_n10_m20_p1_eval", "tsp_n12_m30_p2_spatial_eval", "tsp_n12_m30_p1_unweighted", "mis_n6_m8", "mis_n5_m7_unweighted", "ds_n10_m20_p1",
         "ds_n10_m20_p0_eval", "ds_n100_m300_p1", "sp_n10_m20_unweighted", "st_n10_m20_d3_unweighted",
         "lp_n10_m20_p2", "lp_n64_m192_p2", "lp_n12_m24_p3", "lp_n30_m60_p3", "tsp_n10_m20_p2", "tsp_n12_m30_p2_spatial",
         "mc_n10_m20_p4", "mc_n10_m20_p3_d2", "mc_n10_m20_p2", "mc_n10_m20_p1", "mc_n10_m20_p4_eval",
