@@ -10,32 +10,37 @@ CSRC = os.path.join(ROOT, "graphenvs_amd", "csrc")
 OUT = os.path.join(HERE, "libgraphenvs_emu.so")
 
 
-def build(force=False, extra=(), out=None):
-    global OUT
-    if out is not None:
-        OUT_ = out
-    else:
-        OUT_ = OUT
-    return _build(force, list(extra), OUT_)
+ASAN_OUT = os.path.join(HERE, "libgraphenvs_emu_asan.so")
 
 
-def _build(force, extra, OUT):
+def build(force=False, extra=(), out=None, asan=False):
+    """asan=True: AddressSanitizer beside UBSan (out-of-bounds on the slabs and behind a block's dynamic LDS, which is then a heap
+    block of exactly the requested size); the python that loads it must run under LD_PRELOAD of libasan (asan_preload())."""
+    OUT_ = out if out is not None else (ASAN_OUT if asan else OUT)
+    return _build(force, list(extra), OUT_, asan)
+
+
+def asan_preload():
+    return subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+
+
+def _build(force, extra, OUT, asan=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.h"),
                                                                os.path.join(ROOT, "include", "graphenvs.h")]
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(s) for s in srcs):
         return OUT
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DGE_EMU", "-x", "c++", "-ffp-contract=off",
            "-I" + HERE, "-I" + CSRC, "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
-           "-fsanitize=undefined", "-fno-sanitize-recover=undefined", *extra,
+           "-fsanitize=address,undefined" if asan else "-fsanitize=undefined", "-fno-sanitize-recover=undefined", *extra,
            os.path.join(CSRC, "ge_api.hip"), "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 
 
-def load(extra=(), out=None):
+def load(extra=(), out=None, asan=False):
     sys.path.insert(0, ROOT)
     from graphenvs_amd import _lib
-    return _lib.bind(ctypes.CDLL(build(extra=extra, out=out)))
+    return _lib.bind(ctypes.CDLL(build(extra=extra, out=out, asan=asan)))
 
 
 if __name__ == "__main__":

@@ -10,6 +10,9 @@
 // only opens libgraphenvs_hip.so and raises if it is missing.
 #pragma once
 #include <ucontext.h>
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -82,13 +85,39 @@ struct Block {
 
 inline Block &blk() { static Block b; return b; }
 
-inline void yield_to_sched() { Block &b = blk(); swapcontext(&b.fib[b.cur].ctx, &b.sched); }
+// AddressSanitizer build (build_emu.py asan=True): every switch between the scheduler's stack and a lane's fiber stack is
+// announced, and the dynamic LDS of a block is a heap allocation of exactly the requested size (its red zone is the guard).
+#if defined(__SANITIZE_ADDRESS__)
+#define GE_EMU_ASAN 1
+struct AsanSched { const void *bottom = nullptr; size_t size = 0; };
+inline AsanSched &asan_sched() { static AsanSched a; return a; }
+inline void switch_to_fiber(Block &b, Fiber &f) {
+  void *fake = nullptr;
+  __sanitizer_start_switch_fiber(&fake, f.stack, kStack);
+  swapcontext(&b.sched, &f.ctx);
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+}
+inline void switch_to_sched(Block &b, bool last) {
+  void *fake = nullptr;
+  __sanitizer_start_switch_fiber(last ? nullptr : &fake, asan_sched().bottom, asan_sched().size);
+  swapcontext(&b.fib[b.cur].ctx, &b.sched);
+  __sanitizer_finish_switch_fiber(fake, &asan_sched().bottom, &asan_sched().size);
+}
+inline void fiber_entered() { __sanitizer_finish_switch_fiber(nullptr, &asan_sched().bottom, &asan_sched().size); }
+#else
+inline void switch_to_fiber(Block &b, Fiber &f) { swapcontext(&b.sched, &f.ctx); }
+inline void switch_to_sched(Block &b, bool) { swapcontext(&b.fib[b.cur].ctx, &b.sched); }
+inline void fiber_entered() {}
+#endif
+
+inline void yield_to_sched() { switch_to_sched(blk(), false); }
 
 inline void trampoline() {
+  fiber_entered();
   Block &b = blk();
   b.body();
   b.fib[b.cur].done = true;
-  swapcontext(&b.fib[b.cur].ctx, &b.sched);
+  switch_to_sched(b, true);
 }
 
 inline void die(const char *msg) { fprintf(stderr, "[hip_emu] %s\n", msg); abort(); }
@@ -97,7 +126,13 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
   Block &b = blk();
   static bool reverse = getenv("GE_EMU_REVERSE") && atoi(getenv("GE_EMU_REVERSE"));
   b.nthreads = nthreads; b.bid = bid; b.gdim = gdim;
+#ifdef GE_EMU_ASAN
+  static size_t shortfall = getenv("GE_EMU_LDS_SHORTFALL") ? (size_t)atoi(getenv("GE_EMU_LDS_SHORTFALL")) : 0;  // self-test of the detector: allocate less than asked
+  if (shortfall && smem_bytes > shortfall) smem_bytes -= shortfall;
+  free(b.smem); b.smem = nullptr; if (posix_memalign((void **)&b.smem, 64, smem_bytes ? smem_bytes : 1)) die("out of memory"); b.smem_bytes = smem_bytes;  // exact size: the red zone follows the last byte
+#else
   if (b.smem_bytes < smem_bytes + 64) { free(b.smem); b.smem = (unsigned char *)aligned_alloc(64, ((smem_bytes + 64 + 63) / 64) * 64); b.smem_bytes = smem_bytes + 64; }
+#endif
   memset(b.smem, 0xCD, b.smem_bytes);  // poison: LDS is uninitialised on the GPU
   memset(b.wave_gen, 0, sizeof(b.wave_gen));
   memset(b.part, 0, sizeof(b.part));
@@ -117,7 +152,7 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
       if (f.done) continue;
       live++;
       if (f.waiting) continue;
-      b.cur = t; swapcontext(&b.sched, &f.ctx); progressed = true;
+      b.cur = t; switch_to_fiber(b, f); progressed = true;
     }
     if (!live) break;
     // release rendezvous groups whose every live member has arrived
@@ -138,7 +173,7 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
     if (!progressed && !released) die("deadlock: a barrier or wave collective was not reached by every live lane (divergent rendezvous)");
   }
   // LDS overrun detector: the 64 bytes behind the requested dynamic LDS were poisoned above and must still be
-  for (size_t k = smem_bytes; k < smem_bytes + 64; k++)
+  for (size_t k = smem_bytes; k < b.smem_bytes; k++)
     if (b.smem[k] != 0xCD) { fprintf(stderr, "[hip_emu] block %d wrote past its %zu bytes of dynamic LDS (offset %zu)\n", bid, smem_bytes, k); abort(); }
 }
 

@@ -159,6 +159,34 @@ def test_emulated_state_dict_moves_between_engines(emu):
     hc.check_state_dict_move(ge, "cpu", emu)
 
 
+@pytest.mark.parametrize("kw", [dict(n_nodes=14, n_edges=50, parenting=1), dict(n_nodes=12, n_edges=30, parenting=2, spatial=True)])
+def test_emulated_tsp_baseline_kernels_match_the_checker_through_autoresets(emu, kw):
+    """TSP with is_eval_env: closure + Christofides kernels in full-reset and queue mode; heuristic[] of the running episode and
+    info['heuristic_solution'] of the finished one equal the checker's, slot by slot"""
+    import oracle
+    B, stride = 5, 100
+    env = ge.VectorGraphEnv("TSP-v0", B, device="cpu", _library=emu, obs_mode="flat", seed_stride=stride, is_eval_env=True, **kw)
+    seeds = list(range(3, 3 + B))
+    env.reset(seed=seeds)
+    refs = [oracle.OracleEnv("TSP-v0", is_eval_env=True, **kw) for _ in range(B)]
+    for r, sd in zip(refs, seeds):
+        r.reset(seed=sd)
+    ends = 0
+    for k in range(2 * kw["n_nodes"] + 2):
+        assert env.t["heuristic"].tolist() == [r.heuristic_solution for r in refs], k
+        a = env.sample_random_actions(policy_seed=4).clone()
+        _, rew, term, _, info = env.step(a)
+        for i, r in enumerate(refs):
+            _, rr, dd, _, inf = r.step(int(a[i]))
+            assert rr == float(rew[i]) and dd == bool(term[i])
+            if dd:
+                assert float(info["heuristic_solution"][i]) == inf["heuristic_solution"], (k, i)
+                seeds[i] += stride; r.reset(seed=seeds[i]); ends += 1
+    assert ends >= B and all(r.heuristic_solution > 0 for r in refs)
+    env.check_device_errors()
+    env.close()
+
+
 def test_emulated_unseeded_reset_continues_the_streams_of_every_slot(emu):
     import oracle
     hc.check_continue_streams(ge, oracle, "cpu", emu)
@@ -166,3 +194,24 @@ def test_emulated_unseeded_reset_continues_the_streams_of_every_slot(emu):
 
 def test_emulated_return_graph_obs_and_copy_outputs(emu):
     hc.check_graph_obs(ge, "cpu", emu)
+
+
+def _asan_child(args, env_extra):
+    import subprocess
+    env = dict(os.environ, LD_PRELOAD=build_emu.asan_preload(), ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", **env_extra)
+    build_emu.build(asan=True)
+    return subprocess.run([sys.executable, os.path.join(os.path.dirname(build_emu.OUT), "asan_run.py"), *args], env=env, capture_output=True,
+                          text=True, timeout=1500)
+
+
+def test_emulated_kernels_under_address_sanitizer():
+    """the kernels under AddressSanitizer (slabs and per-block LDS are heap blocks with red zones): golden replays of all
+    nine envs, unseeded reset, inject + autoreset"""
+    r = _asan_child([], {})
+    assert r.returncode == 0 and "ASAN RUN COMPLETE" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_address_sanitizer_harness_sees_an_lds_overrun():
+    """the detector detects: with 64 bytes less LDS than the launch asked for, the same run must die in AddressSanitizer"""
+    r = _asan_child(["sp_n10_m20_eval"], {"GE_EMU_LDS_SHORTFALL": "64"})
+    assert r.returncode != 0 and "AddressSanitizer" in r.stderr, (r.returncode, r.stderr[-2000:])
