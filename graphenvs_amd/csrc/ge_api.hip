@@ -138,6 +138,14 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   return GE_OK;
 }
 
+// per-slot work space of the sequential is_eval_env baselines (ge_tsp_eval.h); 0 = none
+static uint64_t eval_slot_bytes(const GeParams &P) {
+  if (!P.is_eval) return 0;
+  if (P.env_type == GE_TSP) return ge_ch_slot_bytes(P.n);
+  if (P.env_type == GE_MAX_INDEPENDENT_SET && !P.weighted) return ge_cr_slot_bytes(P.n, P.m);
+  return 0;
+}
+
 extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
   GeParams P;
   int rc = derive(cfg, P);
@@ -148,7 +156,7 @@ extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
   out->obs_len = (int64_t)P.n * P.F + (int64_t)P.E * P.Fe + 2 * (int64_t)P.E;
   out->reset_lds_bytes = P.lds.total;
   out->feat_parts = P.feat_parts;
-  out->eval_scratch_bytes = (P.env_type == GE_TSP && P.is_eval) ? (int64_t)((uint64_t)P.B * ge_ch_slot_bytes(P.n)) : 0;
+  out->eval_scratch_bytes = (int64_t)((uint64_t)P.B * eval_slot_bytes(P));
   return GE_OK;
 }
 
@@ -178,7 +186,7 @@ static int check_buffers(const GeParams &P, const ge_buffers *bufs) {
   if (P.env_type == GE_MULTICAST_ROUTING && P.parenting >= 3 && !bufs->node_aux) return fail(GE_E_BADARG, "MulticastRouting parenting >= 3 needs node_aux");
   if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
-  if (P.env_type == GE_TSP && P.is_eval && !bufs->eval_scratch) return fail(GE_E_BADARG, "TSP with is_eval_env needs eval_scratch (ge_layout.eval_scratch_bytes)");
+  if (eval_slot_bytes(P) && !bufs->eval_scratch) return fail(GE_E_BADARG, "is_eval_env of TSP / unweighted MaxIndependentSet needs eval_scratch (ge_layout.eval_scratch_bytes)");
   if (P.W == 1 && !bufs->node_rec) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec");
   return GE_OK;
 }
@@ -367,11 +375,17 @@ static int launch_features(ge_engine *e, int mode, void *stream) {
   return launch_combine(e, mode, stream);
 }
 
-// TSP with is_eval_env: the Christofides baseline of the regenerated slots (ge_tsp_eval.h), on the slabs the graph kernel wrote
-static int launch_tsp_baseline(ge_engine *e, int mode, void *stream) {
+// is_eval_env baselines that are sequential programs (ge_tsp_eval.h: TSP Christofides, MaxIndependentSet clique removal) for the
+// regenerated slots, on the slabs the graph kernel wrote
+static int launch_seq_baseline(ge_engine *e, int mode, void *stream) {
   const GeParams &P = e->P;
-  const uint64_t slot_bytes = ge_ch_slot_bytes(P.n);
+  const uint64_t slot_bytes = eval_slot_bytes(P);
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  if (P.env_type == GE_MAX_INDEPENDENT_SET) {
+    int g = (P.B + GE_TSP_EVAL_THREADS - 1) / GE_TSP_EVAL_THREADS; if (g > 4096) g = 4096;
+    GE_LAUNCH(ge_k_mis_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes);
+    return check_launch("MaxIndependentSet baseline kernel");
+  }
   const int pre_off = GE_WAVE * P.W * 8;
   int grid = P.B < 2048 ? P.B : 2048;
   GE_LAUNCH(ge_k_tsp_closure, grid, GE_TSP_EVAL_THREADS, pre_off + (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes, pre_off);
@@ -401,7 +415,7 @@ static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeI
   else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
   rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;
-  if (mode != GE_RESET_INJECT && e->P.env_type == GE_TSP && e->P.is_eval) rc = launch_tsp_baseline(e, mode == GE_RESET_QUEUE ? mode : (int)GE_RESET_ALL, stream);
+  if (mode != GE_RESET_INJECT && e->n_classes == 0 && eval_slot_bytes(e->P)) rc = launch_seq_baseline(e, mode == GE_RESET_QUEUE ? mode : (int)GE_RESET_ALL, stream);
   if (rc != GE_OK) return rc;
   if (mode != GE_RESET_INJECT) rc = launch_features(e, mode == GE_RESET_CONT ? (int)GE_RESET_ALL : mode, stream);
   if (rc == GE_OK && (mode == GE_RESET_ALL || inj.seeds)) e->seeded = true;

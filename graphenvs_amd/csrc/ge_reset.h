@@ -1270,7 +1270,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     } else if (t == GE_STEINER_TREE && P.n_dests == n - 1) {
       heuristic = ge_mst_total_wave(P, c, env, lane);  // steiner_tree.py:80-81
     } else if (t == GE_DENSEST_SUBGRAPH) heuristic = -1.0;             // densest_subgraph.py:85-88
-    else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : ge_greedy_mis_wave(P, c, lane);  // own greedy in place of clique removal
+    else if (t == GE_MAX_INDEPENDENT_SET) heuristic = P.weighted ? -1.0 : ge_greedy_mis_wave(P, c, lane);  // replaced by ge_k_mis_baseline (clique removal, exactly); this greedy value only stays if its work space were too small
     else if (t == GE_TSP) { const double mst = ge_mst_total_wave(P, c, env, lane); heuristic = mst + mst; }  // own double-tree walk in place of Christofides
     else if (t == GE_STEINER_TREE) heuristic = ge_kou_steiner_wave(P, c, lane);  // own 2-approximation in place of networkx's Kou
     else if (t == GE_MULTICAST_ROUTING) heuristic = 0.0;                 // computed below, after the delay bound

@@ -1,4 +1,5 @@
-// TSP-v0 baseline (is_eval_env only): info['heuristic_solution'] = length of a Christofides tour (tsp.py:114-117 calls
+// Baselines that run as sequential programs, one lane per slot (is_eval_env only).
+// TSP-v0: info['heuristic_solution'] = length of a Christofides tour (tsp.py:114-117 calls
 // nx.approximation.traveling_salesman_problem: all-pairs Dijkstra, Christofides on the metric closure).  Two launches behind the
 // graph kernel, on the slabs it wrote, outside the reset kernels so that the training path (no baseline) carries none of this:
 //   ge_k_tsp_closure  one wave per regenerated slot, one LANE per Dijkstra source: integer distances (weight codes = tenths;
@@ -14,11 +15,15 @@
 
 #ifdef GE_EMU
 #define GE_CH_FN static inline
+#define GE_CR_FN static inline
 #else
 #define GE_CH_FN static __device__
 #define GE_CH_HD static __host__ __device__ inline
+#define GE_CR_FN static __device__
+#define GE_CR_HD static __host__ __device__ inline
 #endif
 #include "ge_christofides.h"
+#include "ge_clique_removal.h"
 
 #define GE_TSP_EVAL_THREADS 64
 
@@ -85,5 +90,27 @@ GE_KERNEL ge_k_tsp_tour(GeParams P, int mode, uint8_t *scratch, uint64_t slot_by
     c.D = (const int32_t *)blk;
     const int64_t tot = ge_christofides_tour(&c);
     if (tot >= 0) P.buf.heuristic[env] = (double)tot / (P.spatial ? 65536.0 : 10.0);  // else: the double-tree walk stays
+  }
+}
+
+// MaxIndependentSet-v0 baseline (is_eval_env, unweighted): len(nx.approximation.maximum_independent_set(G))
+// (max_independent_set.py:63-67), networkx's clique removal reproduced exactly (ge_clique_removal.h: dict orders of the graph
+// copies, CPython's set tables).  One LANE per regenerated slot on the slot's scratch block; replaces the min-degree greedy value
+// the graph kernel left in heuristic[] (which stays if the work space were ever too small).  Evaluation-time path, like the above.
+GE_KERNEL ge_k_mis_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
+  int *pre = (int *)ge_dyn_smem();
+  const int count = ge_tsp_count(P, pre, mode);
+  const int n = P.n;
+  const ge_buffers &G = P.buf;
+  for (int q = ge_bid() * GE_TSP_EVAL_THREADS + ge_tid(); q < count; q += ge_gdim() * GE_TSP_EVAL_THREADS) {
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    ge_cr_work w;
+    ge_cr_carve(&w, scratch + (uint64_t)env * slot_bytes, n, P.m);
+    const int32_t *rp = G.row_ptr + (int64_t)env * (n + 1);
+    const int64_t ebase = (int64_t)env * P.E;
+    for (int v = 0; v <= n; v++) w.ga.off[v] = rp[v];
+    for (int k = 0; k < P.E; k++) w.ga.adj[k] = (uint16_t)(G.colw[ebase + k] >> 4);  // insertion-order columns
+    const int32_t r = ge_cr_solve(&w);
+    if (r >= 0) G.heuristic[env] = (double)r;
   }
 }

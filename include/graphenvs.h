@@ -93,7 +93,9 @@ typedef struct {
   int64_t obs_len;             /* flat obs length per env: n*F + E*Fe + 2E (utils.py:87-88) */
   int64_t reset_lds_bytes;     /* dynamic LDS one reset workgroup needs */
   int32_t feat_parts;          /* workgroups that share one slot in the n > 64 feature kernel (sizes feat_scratch) */
-  int64_t eval_scratch_bytes;  /* bytes of ge_buffers.eval_scratch (TSP with is_eval_env: closure matrix + matching tables per slot; else 0) */
+  int64_t eval_scratch_bytes;  /* bytes of ge_buffers.eval_scratch: work space of the is_eval_env baselines that run as sequential
+                                  programs (TSP: closure matrix + matching tables per slot; unweighted MaxIndependentSet: graph
+                                  copies + set tables of clique removal); else 0 */
 } ge_layout;
 
 /* Device buffers.  B = num_envs, Nn = B*n, Ne = B*E, W = ceil(n/64).
@@ -159,8 +161,8 @@ typedef struct {
   uint32_t *stream_state; /* [B, 2, GE_STREAM_WORDS] optional (may be NULL): the python and the numpy MT19937 stream of every slot as its
                                  last regeneration LEFT them (624 state words, then the read position), written by every reset
                                  when present -- what ge_reset_continue (reset(seed=None), shortest_path.py:49-52) resumes from */
-  uint8_t *eval_scratch;  /* [ge_layout.eval_scratch_bytes] TSP with is_eval_env: work space of the Christofides baseline (tsp.py:114-117);
-                                 else NULL */
+  uint8_t *eval_scratch;  /* [ge_layout.eval_scratch_bytes] is_eval_env work space: TSP's Christofides baseline (tsp.py:114-117),
+                                 MaxIndependentSet's clique removal (max_independent_set.py:63-67); else NULL */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;

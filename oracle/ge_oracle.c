@@ -498,6 +498,68 @@ int64_t oge_debug_min_matching(int32_t k, const int32_t *dist, int32_t *match_ou
   return c.err ? -1 : tot;
 }
 
+/* ------------------------------------------------------------------ MIS baseline: networkx's clique removal, exactly */
+/* max_independent_set.py:63-67: len(nx.approximation.maximum_independent_set(G)).  The restatement (dict orders of networkx's
+ * graph copies, CPython's set tables for ints) is graphenvs_amd/csrc/ge_clique_removal.h, one text for engine and checker; it is
+ * pinned against the interpreter's own sets, against networkx on random graphs and by the reference fixtures (tests/). */
+#include "../graphenvs_amd/csrc/ge_clique_removal.h"
+
+static double clique_removal_baseline(oge_env *e, double fallback) {
+  int n = e->n, m = e->E / 2;
+  uint8_t *work = (uint8_t *)malloc(ge_cr_slot_bytes(n, m));
+  ge_cr_work w;
+  ge_cr_carve(&w, work, n, m);
+  for (int v = 0; v <= n; v++) w.ga.off[v] = e->row_ptr[v];
+  for (int k = 0; k < e->row_ptr[n]; k++) w.ga.adj[k] = (uint16_t)e->col[k];
+  int32_t r = ge_cr_solve(&w);
+  free(work);
+  return r < 0 ? fallback : (double)r;
+}
+
+/* test hooks: iteration order of set(keys) built by insertion; of keys(nodes) - keys(first) - {node} as nx.non_neighbors builds it;
+ * the clique-removal value of a graph given as insertion-order CSR */
+int32_t oge_debug_pyset_int_order(const int32_t *keys, int32_t count, int32_t *out) {
+  uint8_t *buf = (uint8_t *)malloc((size_t)count * 64 + 4096);
+  ge_cr_arena a = {buf, 0, (uint64_t)count * 64 + 4096, 0, 0};
+  ge_pyset s; ge_pyset_init(&a, &s);
+  for (int i = 0; i < count; i++) ge_pyset_add(&a, &s, keys[i]);
+  int w = 0;
+  for (int i = 0; i <= s.mask; i++) if (s.tab[i] >= 0) out[w++] = s.tab[i];
+  int err = a.err; free(buf);
+  return err ? -1 : w;
+}
+
+int32_t oge_debug_non_neighbors(const int32_t *nodes, int32_t k, const int32_t *first_adj, int32_t deg, int32_t *out) {
+  int n = 0;
+  for (int i = 0; i < k; i++) if (nodes[i] >= n) n = nodes[i] + 1;
+  uint8_t *buf = (uint8_t *)malloc((size_t)k * 256 + 8192);
+  ge_cr c; c.n = n; c.W = (n + 63) / 64; c.pos = NULL;
+  c.ar.base = buf; c.ar.top = 0; c.ar.peak = 0; c.ar.cap = (uint64_t)k * 256 + 8192; c.ar.err = 0;
+  ge_cr_graph g; g.k = k;
+  g.nodes = (uint16_t *)malloc((size_t)(k + 1) * 2); g.off = (int32_t *)malloc(8); g.adj = (uint16_t *)malloc((size_t)(deg + 1) * 2);
+  for (int i = 0; i < k; i++) g.nodes[i] = (uint16_t)nodes[i];
+  g.off[0] = 0; g.off[1] = deg;
+  for (int i = 0; i < deg; i++) g.adj[i] = (uint16_t)first_adj[i];
+  uint16_t *o16 = (uint16_t *)malloc((size_t)(k + 1) * 2);
+  int32_t cnt = ge_cr_non_neighbors(&c, &g, o16);
+  for (int i = 0; i < cnt; i++) out[i] = o16[i];
+  int err = c.ar.err;
+  free(buf); free(g.nodes); free(g.off); free(g.adj); free(o16);
+  return err ? -1 : cnt;
+}
+
+int32_t oge_debug_clique_removal(int32_t n, int32_t m, const int32_t *row_ptr, const int32_t *col) {
+  uint8_t *work = (uint8_t *)malloc(ge_cr_slot_bytes(n, m));
+  ge_cr_work w;
+  ge_cr_carve(&w, work, n, m);
+  for (int v = 0; v <= n; v++) w.ga.off[v] = row_ptr[v];
+  for (int k = 0; k < row_ptr[n]; k++) w.ga.adj[k] = (uint16_t)col[k];
+  int32_t r = ge_cr_solve(&w);
+  if (getenv("OGE_CR_PEAK")) fprintf(stderr, "cr n %d m %d peak %llu cap %llu\n", n, m, (unsigned long long)w.c.ar.peak, (unsigned long long)w.c.ar.cap);
+  free(work);
+  return r;
+}
+
 /* ------------------------------------------------------------------ masks */
 /* BFS reach set from `from` inside alive nodes, optionally without `skip` */
 static int residual_reach(oge_env *e, int from, int skip, uint8_t *seen) {
@@ -1009,7 +1071,8 @@ int oge_reset(oge_env *e, int64_t seed) {
     build_directed(e);
     for (int v = 0; v < n; v++) e->x[v * F + 0] = (float)cost[v];
     for (int p = 0; p < e->E; p++) e->ef[p] = 1.f;
-    e->heuristic = e->cfg.is_eval_env ? (e->cfg.weighted ? -1.0 : greedy_mis_size(e, NULL)) : 0.0; e->head = -1; /* own greedy in place of clique removal */
+    /* max_independent_set.py:63-67: clique removal, exactly (the min-degree greedy set only if the work space were ever too small) */
+    e->heuristic = e->cfg.is_eval_env ? (e->cfg.weighted ? -1.0 : clique_removal_baseline(e, greedy_mis_size(e, NULL))) : 0.0; e->head = -1;
   }
   generate_features(e, pr_weighted);
   compute_mask(e);

@@ -100,6 +100,12 @@ double oge_debug_steiner_tree(oge_env *e, uint8_t *out_nn);
  * of a perfect matching of dist [k*k] (k even) with every vertex's partner in match_out [k] */
 int64_t oge_debug_christofides(int32_t n, const int32_t *D);
 int64_t oge_debug_min_matching(int32_t k, const int32_t *dist, int32_t *match_out);
+/* the MIS baseline's pieces (graphenvs_amd/csrc/ge_clique_removal.h): iteration order of a CPython set of ints built by insertion;
+ * of nx.non_neighbors(G, nodes[0]) for a graph whose node dict is `nodes` and whose first adjacency dict is `first_adj`; the value
+ * len(nx.approximation.maximum_independent_set(G)) for G as insertion-order CSR (-1: work space too small) */
+int32_t oge_debug_pyset_int_order(const int32_t *keys, int32_t count, int32_t *out);
+int32_t oge_debug_non_neighbors(const int32_t *nodes, int32_t k, const int32_t *first_adj, int32_t deg, int32_t *out);
+int32_t oge_debug_clique_removal(int32_t n, int32_t m, const int32_t *row_ptr, const int32_t *col);
 
 /* iteration order of a CPython 3.10 set after adding the int pairs (u[i], v[i]) in order (multicast baseline sums a set) */
 int oge_pyset_order(const int32_t *u, const int32_t *v, int count, int32_t *out_u, int32_t *out_v);

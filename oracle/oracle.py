@@ -39,7 +39,8 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "ge_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ge_oracle.h")),
-            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_christofides.h"))):
+            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_christofides.h")),
+            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_clique_removal.h"))):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libge_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -87,6 +88,12 @@ def lib():
         L.oge_debug_christofides.argtypes = [i32, vp]
         L.oge_debug_min_matching.restype = i64
         L.oge_debug_min_matching.argtypes = [i32, vp, vp]
+        L.oge_debug_pyset_int_order.restype = i32
+        L.oge_debug_pyset_int_order.argtypes = [vp, i32, vp]
+        L.oge_debug_non_neighbors.restype = i32
+        L.oge_debug_non_neighbors.argtypes = [vp, i32, vp, i32, vp]
+        L.oge_debug_clique_removal.restype = i32
+        L.oge_debug_clique_removal.argtypes = [i32, i32, vp, vp]
         L.oge_pyset_order.restype = C.c_int
         L.oge_pyset_order.argtypes = [vp, vp, C.c_int, vp, vp]
         L.oge_mt_py_seed.argtypes = [vp, C.c_uint32]
@@ -265,3 +272,25 @@ def min_matching(dist):
     dist = np.ascontiguousarray(dist, dtype=np.int32)
     out = np.zeros(dist.shape[0], dtype=np.int32)
     return int(lib().oge_debug_min_matching(dist.shape[0], dist.ctypes.data, out.ctypes.data)), out
+
+
+def pyset_int_order(keys):
+    """iteration order of set() after adding the ints `keys` in order, by the checker's restatement of setobject.c"""
+    k = np.ascontiguousarray(keys, dtype=np.int32); out = np.zeros(max(1, len(k)), dtype=np.int32)
+    n = lib().oge_debug_pyset_int_order(k.ctypes.data, len(k), out.ctypes.data)
+    assert n >= 0
+    return out[:n].tolist()
+
+
+def non_neighbors_order(nodes, first_adj):
+    """iteration order of nx.non_neighbors(G, nodes[0]) for a graph with node dict order `nodes` and G.adj[nodes[0]] order `first_adj`"""
+    a = np.ascontiguousarray(nodes, dtype=np.int32); b = np.ascontiguousarray(first_adj, dtype=np.int32)
+    out = np.zeros(max(1, len(a)), dtype=np.int32)
+    n = lib().oge_debug_non_neighbors(a.ctypes.data, len(a), b.ctypes.data, len(b), out.ctypes.data)
+    assert n >= 0
+    return out[:n].tolist()
+
+
+def clique_removal_len(n, row_ptr, col):
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int32); c = np.ascontiguousarray(col, dtype=np.int32)
+    return int(lib().oge_debug_clique_removal(n, len(c) // 2, rp.ctypes.data, c.ctypes.data))

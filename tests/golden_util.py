@@ -36,8 +36,6 @@ def heuristic_kind(env_id, kwargs):
         return "steiner2"
     if env_id == "TSP-v0":
         return "christofides"
-    if env_id == "MaxIndependentSet-v0" and not kwargs.get("weighted", True):
-        return "mis"
     return "exact"
 
 

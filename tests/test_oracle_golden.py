@@ -123,20 +123,61 @@ def _nx_graph(env):
     return G
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_own_greedy_mis_is_a_maximal_independent_set_within_the_optimum(seed):
-    import itertools
-    env = oracle.OracleEnv("MaxIndependentSet-v0", n_nodes=12, n_edges=20, weighted=False, is_eval_env=True)
+def test_int_set_restatement_matches_the_interpreter():
+    """graphenvs_amd/csrc/ge_clique_removal.h restates CPython's setobject.c for int keys: iteration order of set(list), and of
+    `d.keys() - a.keys() - {x}` as nx.non_neighbors builds it (PySet_New(dict), difference_update, set.__sub__: linear probes,
+    dummies, the resize rules, set_merge's copy paths), against the running interpreter's own sets"""
+    import random
+    rng = random.Random(5)
+    for t in range(1500):
+        n = rng.choice([3, 8, 20, 64, 130, 512, 1000, 4000])
+        keys = rng.sample(range(n), rng.randint(0, min(n, rng.choice([5, 10, 40, 200, 2000]))))
+        assert list(set(keys)) == oracle.pyset_int_order(keys), (t, len(keys))
+    for t in range(2500):
+        n = rng.choice([3, 6, 9, 17, 33, 64, 100, 257, 600])
+        k = rng.randint(1, n)
+        nodes = rng.sample(range(n), k)
+        if rng.random() < 0.5:
+            nodes.sort()
+        deg = rng.randint(0, k - 1) if rng.random() < 0.7 else rng.randint(max(0, k - 3), k - 1)
+        adj = rng.sample(nodes[1:], deg)
+        want = list(dict.fromkeys(nodes).keys() - dict.fromkeys(adj).keys() - {nodes[0]})
+        assert want == oracle.non_neighbors_order(nodes, adj), (t, k, deg)
+
+
+def test_mis_baseline_is_networkx_clique_removal_exactly():
+    """len(nx.approximation.maximum_independent_set(G)) (max_independent_set.py:63-67) on random graphs, sparse to dense: the value
+    hangs on dict orders of graph copies and on set iteration orders, all restated"""
+    nx = pytest.importorskip("networkx")
+    import random
+    rng = random.Random(7)
+    for t in range(120):
+        n = rng.choice([5, 8, 12, 20, 33, 64, 90, 130])
+        m = rng.randint(n - 1, min(n * (n - 1) // 2, rng.choice([2, 3, 4, 8]) * n))
+        G = nx.gnm_random_graph(n, m, seed=t)
+        rp, col = [0], []
+        for v in range(n):
+            col += list(G.adj[v]); rp.append(len(col))
+        assert oracle.clique_removal_len(n, rp, col) == len(nx.approximation.maximum_independent_set(G)), (t, n, m)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_mis_env_baseline_equals_networkx_on_the_env_graph(seed):
+    """the env's heuristic_solution against networkx run on a graph with the env graph's node and adjacency dict orders"""
+    nx = pytest.importorskip("networkx")
+    n = 40
+    env = oracle.OracleEnv("MaxIndependentSet-v0", n_nodes=n, n_edges=100, weighted=False, is_eval_env=True)
     env.reset(seed=seed)
-    size, member = env.debug_greedy_mis()
-    G = _nx_graph(env)
-    S = set(np.nonzero(member)[0].tolist())
-    assert size == len(S) == env.heuristic_solution
-    assert not any(G.has_edge(u, v) for u, v in itertools.combinations(S, 2))            # independent
-    assert all(any(G.has_edge(v, u) for u in S) for v in G if v not in S)                 # maximal
-    alpha = max(len(c) for k in range(1, 13) for c in itertools.combinations(range(12), k)
-                if not any(G.has_edge(u, v) for u, v in itertools.combinations(c, 2)))
-    assert len(S) <= alpha and len(S) >= 12 / (max(d for _, d in G.degree()) + 1)
+    rows = {v: [] for v in range(n)}
+    for a, b in env.edge_links():  # row-major by source, insertion-order columns (SURVEY 9.2)
+        rows[int(a)].append(int(b))
+    H = nx.Graph()
+    H.add_nodes_from(range(n))
+    H._adj = {v: {w: {} for w in rows[v]} for v in range(n)}  # the adjacency dicts in exactly these orders
+    rp, col = [0], []
+    for v in range(n):
+        col += rows[v]; rp.append(len(col))
+    assert env.heuristic_solution == len(nx.approximation.maximum_independent_set(H)) == oracle.clique_removal_len(n, rp, col)
 
 
 @pytest.mark.parametrize("seed", range(6))
