@@ -26,9 +26,9 @@ def sha64(a):
 
 
 def heuristic_kind(env_id, kwargs):
-    """how info['heuristic_solution'] relates to the reference's: "exact", or -- for the three baselines SURVEY 8(f)-3 asks
-    bound checks for (networkx Kou Steiner tree, Christofides tour, clique-removal independent set), which the oracle and
-    the engine replace with their own deterministic heuristics of the same kind -- the bound that must hold"""
+    """how info['heuristic_solution'] relates to the reference's: "exact" (Dijkstra, MST, constants, networkx's clique-removal
+    independent set), or -- for the Kou Steiner tree and the Christofides tour, which networkx tie-breaks through dict orders and the
+    oracle and the engine replace with deterministic heuristics of the same kind -- the bound that must hold"""
     n = kwargs["n_nodes"]
     if not kwargs.get("is_eval_env", False):
         return "exact"  # every baseline is 0 (or its constant) when it is not computed
