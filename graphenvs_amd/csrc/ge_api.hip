@@ -143,6 +143,7 @@ static uint64_t eval_slot_bytes(const GeParams &P) {
   if (!P.is_eval) return 0;
   if (P.env_type == GE_TSP) return ge_ch_slot_bytes(P.n);
   if (P.env_type == GE_MAX_INDEPENDENT_SET && !P.weighted) return ge_cr_slot_bytes(P.n, P.m);
+  if (P.env_type == GE_STEINER_TREE && P.n_dests > 1 && P.n_dests < P.n - 1) return ge_steiner_slot_bytes(P.n, P.m, P.T);  // steiner_tree.py:78-87: the Kou branch
   return 0;
 }
 
@@ -186,7 +187,7 @@ static int check_buffers(const GeParams &P, const ge_buffers *bufs) {
   if (P.env_type == GE_MULTICAST_ROUTING && P.parenting >= 3 && !bufs->node_aux) return fail(GE_E_BADARG, "MulticastRouting parenting >= 3 needs node_aux");
   if (P.feat_parts > 1 && !bufs->feat_scratch) return fail(GE_E_BADARG, "feat_scratch required (ge_layout.feat_parts > 1)");
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
-  if (eval_slot_bytes(P) && !bufs->eval_scratch) return fail(GE_E_BADARG, "is_eval_env of TSP / unweighted MaxIndependentSet needs eval_scratch (ge_layout.eval_scratch_bytes)");
+  if (eval_slot_bytes(P) && !bufs->eval_scratch) return fail(GE_E_BADARG, "is_eval_env of TSP / unweighted MaxIndependentSet / SteinerTree (1 < n_dests < n - 1) needs eval_scratch (ge_layout.eval_scratch_bytes)");
   if (P.W == 1 && !bufs->node_rec) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec");
   return GE_OK;
 }
@@ -385,6 +386,11 @@ static int launch_seq_baseline(ge_engine *e, int mode, void *stream) {
     int g = (P.B + GE_TSP_EVAL_THREADS - 1) / GE_TSP_EVAL_THREADS; if (g > 4096) g = 4096;
     GE_LAUNCH(ge_k_mis_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes);
     return check_launch("MaxIndependentSet baseline kernel");
+  }
+  if (P.env_type == GE_STEINER_TREE) {
+    int g = (P.B + GE_TSP_EVAL_THREADS - 1) / GE_TSP_EVAL_THREADS; if (g > 4096) g = 4096;
+    GE_LAUNCH(ge_k_steiner_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes);
+    return check_launch("SteinerTree baseline kernel");
   }
   const int pre_off = GE_WAVE * P.W * 8;
   int grid = P.B < 2048 ? P.B : 2048;

@@ -123,26 +123,31 @@ GE_CR_FN void ge_pyset_from_dict(ge_cr_arena *a, ge_pyset *s, const uint16_t *ke
   for (int32_t i = 0; i < count && !a->err; i++) ge_pyset_add(a, s, keys[i]);
 }
 
+/* set(so) / so.copy(): set_merge into a new, empty set */
+GE_CR_FN void ge_pyset_copy(ge_cr_arena *a, const ge_pyset *so, ge_pyset *res) {
+  ge_pyset_init(a, res);
+  if (a->err || !so->used) return;
+  if ((int64_t)(res->fill + so->used) * 5 >= (int64_t)res->mask * 3) ge_pyset_resize(a, res, (res->used + so->used) * 2);
+  if (a->err) return;
+  if (res->mask == so->mask && so->fill == so->used) {  /* same size, no dummies: the table is copied as it is */
+    for (int32_t i = 0; i <= so->mask; i++) res->tab[i] = so->tab[i];
+    res->fill = so->fill; res->used = so->used;
+  } else {  /* empty target: set_insert_clean in table order */
+    res->fill = so->used; res->used = so->used;
+    for (int32_t i = 0; i <= so->mask; i++) if (so->tab[i] >= 0) ge_pyset_insert_clean(res->tab, res->mask, so->tab[i]);
+  }
+}
+
 /* so - {key} (set_sub -> set_difference with a one-element set) */
 GE_CR_FN void ge_pyset_minus_one(ge_cr_arena *a, const ge_pyset *so, int32_t key, ge_pyset *res) {
-  ge_pyset_init(a, res);
-  if (a->err) return;
-  if ((so->used >> 2) > 1) {  /* set_copy_and_difference: set_copy = set_merge into an empty set, then discard */
-    if (so->used) {
-      if ((int64_t)(res->fill + so->used) * 5 >= (int64_t)res->mask * 3) ge_pyset_resize(a, res, (res->used + so->used) * 2);
-      if (a->err) return;
-      if (res->mask == so->mask && so->fill == so->used) {  /* same size, no dummies: the table is copied as it is */
-        for (int32_t i = 0; i <= so->mask; i++) res->tab[i] = so->tab[i];
-        res->fill = so->fill; res->used = so->used;
-      } else {  /* empty target: set_insert_clean in table order */
-        res->fill = so->used; res->used = so->used;
-        for (int32_t i = 0; i <= so->mask; i++) if (so->tab[i] >= 0) ge_pyset_insert_clean(res->tab, res->mask, so->tab[i]);
-      }
-    }
+  if ((so->used >> 2) > 1) {  /* set_copy_and_difference: set_copy, then discard */
+    ge_pyset_copy(a, so, res);
+    if (a->err) return;
     ge_pyset_discard(res, key);
     ge_pyset_drop_dummies(a, res);
     return;
   }
+  ge_pyset_init(a, res);
   for (int32_t i = 0; i <= so->mask && !a->err; i++) if (so->tab[i] >= 0 && so->tab[i] != key) ge_pyset_add(a, res, so->tab[i]);
 }
 

@@ -24,6 +24,7 @@
 #endif
 #include "ge_christofides.h"
 #include "ge_clique_removal.h"
+#include "ge_kou_exact.h"
 
 #define GE_TSP_EVAL_THREADS 64
 
@@ -112,5 +113,35 @@ GE_KERNEL ge_k_mis_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slo
     for (int k = 0; k < P.E; k++) w.ga.adj[k] = (uint16_t)(G.colw[ebase + k] >> 4);  // insertion-order columns
     const int32_t r = ge_cr_solve(&w);
     if (r >= 0) G.heuristic[env] = (double)r;
+  }
+}
+
+// SteinerTree-v0 baseline (is_eval_env, 1 < n_dests < n - 1): the sum of delays over networkx's Kou Steiner tree
+// (steiner_tree.py:84-87), reproduced exactly (ge_kou_exact.h: heap-ordered Dijkstra paths, stable Kruskal order over subgraph
+// views, CPython's set tables for tuples and ints, float64 sum order).  One LANE per regenerated slot; replaces the own Kou-style
+// value the graph kernel left in heuristic[] (which stays if the work space were ever too small).
+GE_HOSTDEV uint64_t ge_steiner_slot_bytes(int n, int m, int T) {
+  return ((((uint64_t)(2 * m + 1) * 2) + 7) & ~7ull) + (uint64_t)(2 * m + 1) * 8 + ge_kou_arena_bytes(n, m, T);
+}
+
+GE_KERNEL ge_k_steiner_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
+  int *pre = (int *)ge_dyn_smem();
+  const int count = ge_tsp_count(P, pre, mode);
+  const int n = P.n;
+  const ge_buffers &G = P.buf;
+  for (int q = ge_bid() * GE_TSP_EVAL_THREADS + ge_tid(); q < count; q += ge_gdim() * GE_TSP_EVAL_THREADS) {
+    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    uint8_t *blk = scratch + (uint64_t)env * slot_bytes;
+    uint16_t *adj = (uint16_t *)blk;
+    double *w = (double *)(blk + ((((uint64_t)(2 * P.m + 1) * 2) + 7) & ~7ull));
+    const int64_t ebase = (int64_t)env * P.E;
+    for (int k = 0; k < P.E; k++) { const uint16_t cw = G.colw[ebase + k]; adj[k] = (uint16_t)(cw >> 4); w[k] = ge_wlut(cw & 15); }
+    ge_cr_arena a;
+    a.base = (uint8_t *)(w + (2 * P.m + 1)); a.top = 0; a.peak = 0; a.cap = ge_kou_arena_bytes(n, P.m, P.T); a.err = 0;
+    ge_kou_in g;
+    g.n = n; g.m = P.m; g.T = P.T; g.off = G.row_ptr + (int64_t)env * (n + 1); g.adj = adj; g.w = w; g.terms = G.terminals + (int64_t)env * P.T;
+    int err = 0;
+    const double v = ge_kou_exact(&g, &a, &err);
+    if (!err) G.heuristic[env] = v;
   }
 }

@@ -560,6 +560,40 @@ int32_t oge_debug_clique_removal(int32_t n, int32_t m, const int32_t *row_ptr, c
   return r;
 }
 
+/* ------------------------------------------------------------------ SteinerTree baseline: networkx's Kou tree, exactly */
+/* steiner_tree.py:84-87.  The restatement is graphenvs_amd/csrc/ge_kou_exact.h (one text for engine and checker, pinned against
+ * networkx on random graphs and by the reference fixtures). */
+#include "../graphenvs_amd/csrc/ge_kou_exact.h"
+
+static double kou_exact_on(int n, int m, int T, const int32_t *off, const int32_t *col, const double *w, const int32_t *terms, int *err) {
+  uint64_t cap = ge_kou_arena_bytes(n, m, T);
+  uint8_t *buf = (uint8_t *)malloc(cap + (size_t)(2 * m + 2) * 2);
+  uint16_t *adj = (uint16_t *)(buf + cap);
+  for (int k = 0; k < 2 * m; k++) adj[k] = (uint16_t)col[k];
+  ge_cr_arena a = {buf, 0, cap, 0, 0};
+  ge_kou_in g = {n, m, T, off, adj, w, terms};
+  double v = ge_kou_exact(&g, &a, err);
+  if (getenv("OGE_CR_PEAK")) fprintf(stderr, "kou n %d m %d T %d peak %llu cap %llu\n", n, m, T, (unsigned long long)a.peak, (unsigned long long)cap);
+  free(buf);
+  return v;
+}
+
+static double kou_exact_baseline(oge_env *e, double fallback) {
+  int err = 0;
+  int32_t *terms = (int32_t *)malloc((size_t)(e->n_targets + 1) * sizeof(int32_t));
+  for (int i = 0; i <= e->n_targets; i++) terms[i] = e->terms[i];
+  double v = kou_exact_on(e->n, e->E / 2, e->n_targets + 1, e->row_ptr, e->col, e->w64, terms, &err);
+  free(terms);
+  return err ? fallback : v;
+}
+
+/* test hook: the value for a graph given as insertion-order CSR with float64 weights per directed entry; NaN: arena too small */
+double oge_debug_kou_exact(int32_t n, int32_t m, int32_t T, const int32_t *off, const int32_t *col, const double *w, const int32_t *terms) {
+  int err = 0;
+  double v = kou_exact_on(n, m, T, off, col, w, terms, &err);
+  return err ? NAN : v;
+}
+
 /* ------------------------------------------------------------------ masks */
 /* BFS reach set from `from` inside alive nodes, optionally without `skip` */
 static int residual_reach(oge_env *e, int from, int skip, uint8_t *seen) {
@@ -976,7 +1010,7 @@ int oge_reset(oge_env *e, int64_t seed) {
     if (e->cfg.is_eval_env) { /* steiner_tree.py:77-85 */
       if (e->cfg.n_dests == 1) e->heuristic = dijkstra(e, e->terms[0], e->terms[1]);
       else if (e->cfg.n_dests == n - 1) e->heuristic = mst_total(e);
-      else e->heuristic = kou_style_steiner(e, NULL); /* own 2-approximation in place of networkx's Kou (bound-checked) */
+      else e->heuristic = kou_exact_baseline(e, kou_style_steiner(e, NULL)); /* :84-87, networkx's Kou tree exactly (own Kou-style tree only if the work space were too small) */
     }
     e->x[e->src * F + 0] = 1.f;
     for (int i = 1; i <= e->n_targets; i++) e->x[e->terms[i] * F + 1] = 1.f;

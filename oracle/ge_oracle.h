@@ -106,6 +106,9 @@ int64_t oge_debug_min_matching(int32_t k, const int32_t *dist, int32_t *match_ou
 int32_t oge_debug_pyset_int_order(const int32_t *keys, int32_t count, int32_t *out);
 int32_t oge_debug_non_neighbors(const int32_t *nodes, int32_t k, const int32_t *first_adj, int32_t deg, int32_t *out);
 int32_t oge_debug_clique_removal(int32_t n, int32_t m, const int32_t *row_ptr, const int32_t *col);
+/* the SteinerTree baseline (graphenvs_amd/csrc/ge_kou_exact.h) on a graph given as insertion-order CSR with float64 weights per
+ * directed entry and the terminals in self.dests order; NaN: work space too small */
+double oge_debug_kou_exact(int32_t n, int32_t m, int32_t T, const int32_t *off, const int32_t *col, const double *w, const int32_t *terms);
 
 /* iteration order of a CPython 3.10 set after adding the int pairs (u[i], v[i]) in order (multicast baseline sums a set) */
 int oge_pyset_order(const int32_t *u, const int32_t *v, int count, int32_t *out_u, int32_t *out_v);

@@ -40,7 +40,8 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ge_oracle.h")),
             os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_christofides.h")),
-            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_clique_removal.h"))):
+            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_clique_removal.h")),
+            os.path.getmtime(os.path.join(_HERE, "..", "graphenvs_amd", "csrc", "ge_kou_exact.h"))):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libge_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -94,6 +95,8 @@ def lib():
         L.oge_debug_non_neighbors.argtypes = [vp, i32, vp, i32, vp]
         L.oge_debug_clique_removal.restype = i32
         L.oge_debug_clique_removal.argtypes = [i32, i32, vp, vp]
+        L.oge_debug_kou_exact.restype = dbl
+        L.oge_debug_kou_exact.argtypes = [i32, i32, i32, vp, vp, vp, vp]
         L.oge_pyset_order.restype = C.c_int
         L.oge_pyset_order.argtypes = [vp, vp, C.c_int, vp, vp]
         L.oge_mt_py_seed.argtypes = [vp, C.c_uint32]
@@ -294,3 +297,10 @@ def non_neighbors_order(nodes, first_adj):
 def clique_removal_len(n, row_ptr, col):
     rp = np.ascontiguousarray(row_ptr, dtype=np.int32); c = np.ascontiguousarray(col, dtype=np.int32)
     return int(lib().oge_debug_clique_removal(n, len(c) // 2, rp.ctypes.data, c.ctypes.data))
+
+
+def kou_exact(n, row_ptr, col, w, terms):
+    """sum of delays over networkx's Kou Steiner tree, by the checker's restatement (graph as insertion-order CSR)"""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int32); c = np.ascontiguousarray(col, dtype=np.int32)
+    ww = np.ascontiguousarray(w, dtype=np.float64); t = np.ascontiguousarray(terms, dtype=np.int32)
+    return float(lib().oge_debug_kou_exact(n, len(c) // 2, len(t), rp.ctypes.data, c.ctypes.data, ww.ctypes.data, t.ctypes.data))

@@ -27,13 +27,12 @@ def sha64(a):
 
 def heuristic_kind(env_id, kwargs):
     """how info['heuristic_solution'] relates to the reference's: "exact" (Dijkstra, MST, constants, networkx's clique-removal
-    independent set), or -- for the Kou Steiner tree and the Christofides tour, which networkx tie-breaks through dict orders and the
-    oracle and the engine replace with deterministic heuristics of the same kind -- the bound that must hold"""
+    independent set and Kou Steiner tree, both reproduced with their dict / set orders), or -- for the Christofides tour, whose
+    blossom matching networkx tie-breaks through dict orders and the oracle and the engine replace with an own Christofides tour
+     -- the bound that must hold"""
     n = kwargs["n_nodes"]
     if not kwargs.get("is_eval_env", False):
         return "exact"  # every baseline is 0 (or its constant) when it is not computed
-    if env_id == "SteinerTree-v0" and 1 < kwargs.get("n_dests", 3) < n - 1:
-        return "steiner2"
     if env_id == "TSP-v0":
         return "christofides"
     return "exact"

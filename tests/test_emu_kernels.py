@@ -161,10 +161,12 @@ def test_emulated_state_dict_moves_between_engines(emu):
 
 @pytest.mark.parametrize("env_id,kw", [("TSP-v0", dict(n_nodes=14, n_edges=50, parenting=1)), ("TSP-v0", dict(n_nodes=12, n_edges=30, parenting=2, spatial=True)),
                                        ("MaxIndependentSet-v0", dict(n_nodes=20, n_edges=45, weighted=False)),
-                                       ("MaxIndependentSet-v0", dict(n_nodes=36, n_edges=80, weighted=False))])
+                                       ("MaxIndependentSet-v0", dict(n_nodes=36, n_edges=80, weighted=False)),
+                                       ("SteinerTree-v0", dict(n_nodes=16, n_edges=36, n_dests=4)),
+                                       ("SteinerTree-v0", dict(n_nodes=30, n_edges=70, n_dests=20, weighted=False))])
 def test_emulated_sequential_baseline_kernels_match_the_checker_through_autoresets(emu, env_id, kw):
-    """is_eval_env of TSP (closure + Christofides kernels) and of unweighted MaxIndependentSet (clique removal kernel), in full-reset and
-    queue mode: heuristic[] of the running episode and info['heuristic_solution'] of the finished one equal the checker's, slot by slot"""
+    """is_eval_env of TSP (closure + Christofides kernels), of unweighted MaxIndependentSet (clique removal kernel) and of SteinerTree
+    (Kou kernel), in full-reset and queue mode: heuristic[] of the running episode and info['heuristic_solution'] of the finished one equal the checker's, slot by slot"""
     import oracle
     B, stride = 5, 100
     env = ge.VectorGraphEnv(env_id, B, device="cpu", _library=emu, obs_mode="flat", seed_stride=stride, is_eval_env=True, **kw)

@@ -180,8 +180,52 @@ def test_mis_env_baseline_equals_networkx_on_the_env_graph(seed):
     assert env.heuristic_solution == len(nx.approximation.maximum_independent_set(H)) == oracle.clique_removal_len(n, rp, col)
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_own_steiner_heuristic_is_a_tree_over_the_terminals_within_twice_the_optimum(seed):
+def test_steiner_baseline_is_networkx_kou_exactly():
+    """sum of delays over nx...steiner_tree(G, dests, weight='delay', method='kou') (steiner_tree.py:84-87), float64 sum order
+    included, on random connected graphs (weighted in tenths, and unweighted: every tie there is)"""
+    nx = pytest.importorskip("networkx")
+    import math
+    import random
+    rng = random.Random(3); nrng = np.random.RandomState(3)
+    for t in range(150):
+        n = rng.choice([6, 10, 14, 20, 30, 40, 64, 100])
+        m = min(rng.randint(int(0.8 * n * math.log(n)) + 2, int(1.6 * n * math.log(n)) + 4), n * (n - 1) // 2)
+        while True:
+            G = nx.gnm_random_graph(n, m, seed=rng.randint(0, 10 ** 9))
+            if nx.is_connected(G):
+                break
+        delay = nrng.randint(3, 10, size=(n, n)) / 10.0 if t % 5 else np.ones((n, n))
+        for u, v, d in G.edges(data=True):
+            d["delay"] = delay[u, v]
+        dests = nrng.choice(n, rng.randint(3, max(3, n - 2)), replace=False)
+        T = nx.algorithms.approximation.steinertree.steiner_tree(G, dests, weight="delay", method="kou")
+        ref = sum([G[u][v]["delay"] for u, v in T.edges()])
+        rp, col, w = [0], [], []
+        for v in range(n):
+            for u in G.adj[v]:
+                col.append(u); w.append(G[v][u]["delay"])
+            rp.append(len(col))
+        assert oracle.kou_exact(n, rp, col, w, [int(x) for x in dests]) == ref, (t, n, m)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_steiner_env_baseline_equals_networkx_on_the_env_graph(seed):
+    """the env's heuristic_solution against networkx run on a graph with the env graph's node / adjacency dict orders and weights"""
+    nx = pytest.importorskip("networkx")
+    n = 24
+    env = oracle.OracleEnv("SteinerTree-v0", n_nodes=n, n_edges=60, n_dests=6, is_eval_env=True)
+    env.reset(seed=seed)
+    H = nx.Graph()
+    H.add_nodes_from(range(n))
+    for (a, b), d in zip(env.edge_links(), env.edges()[:, 0]):  # row-major by source, insertion-order columns
+        H._adj[int(a)][int(b)] = H._adj[int(b)].get(int(a), {"delay": round(float(d), 1)})
+    T = nx.algorithms.approximation.steinertree.steiner_tree(H, np.array([int(t) for t in env.terminals()]), weight="delay", method="kou")
+    assert env.heuristic_solution == sum([H[u][v]["delay"] for u, v in T.edges()])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_own_steiner_fallback_is_a_tree_over_the_terminals_within_twice_the_optimum(seed):
+    """the Kou-style tree of round 1 stays as the value reported if the exact restatement's work space were ever too small"""
     import itertools
     import networkx as nx
     env = oracle.OracleEnv("SteinerTree-v0", n_nodes=10, n_edges=18, n_dests=3, is_eval_env=True)
@@ -192,7 +236,7 @@ def test_own_steiner_heuristic_is_a_tree_over_the_terminals_within_twice_the_opt
     T = nx.Graph([(u, v) for u in range(10) for v in range(u + 1, 10) if adj[u, v]])
     assert all(G.has_edge(u, v) for u, v in T.edges) and nx.is_tree(T) and all(t in T for t in terms)
     assert all(T.degree(v) > 1 for v in T if v not in terms)                                # no non-terminal leaf
-    assert cost == env.heuristic_solution and abs(cost - sum(G[u][v]["delay"] for u, v in T.edges)) < 1e-6
+    assert abs(cost - sum(G[u][v]["delay"] for u, v in T.edges)) < 1e-6
     others = [v for v in range(10) if v not in terms]
     opt = min(nx.minimum_spanning_tree(G.subgraph(terms + list(extra)), weight="delay").size(weight="delay")
               for k in range(len(others) + 1) for extra in itertools.combinations(others, k)
