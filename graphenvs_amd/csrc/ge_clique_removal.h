@@ -287,7 +287,8 @@ GE_CR_HD uint64_t ge_cr_arena_bytes(int n, int m) {
   return 24ull * (uint64_t)n * (uint64_t)n + 16ull * (uint64_t)(n + 2 * m) + 65536ull;
 }
 GE_CR_HD uint64_t ge_cr_slot_bytes(int n, int m) {
-  return 2 * ge_cr_graph_bytes(n, m) + ge_cr_frames_bytes(n) + (((uint64_t)n * 2 + 7) & ~7ull) + ge_cr_arena_bytes(n, m);
+  const uint64_t bytes = 2 * ge_cr_graph_bytes(n, m) + ge_cr_frames_bytes(n) + (((uint64_t)n * 2 + 7) & ~7ull) + ge_cr_arena_bytes(n, m);
+  return (bytes + 15u) & ~(uint64_t)15u;  /* slot blocks follow one another: keep them aligned */
 }
 
 /* Work space of one slot, carved: the caller fills g0 (nodes 0 .. n-1 in order, off[] / adj[] = the graph's insertion-order

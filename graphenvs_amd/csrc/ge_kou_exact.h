@@ -140,7 +140,8 @@ GE_CR_HD uint64_t ge_kou_arena_bytes(int n, int m, int T) {
   const uint64_t pairs = (uint64_t)T * (uint64_t)(T - 1) / 2;
   uint64_t tuples = 8; while (tuples <= 8ull * (uint64_t)(n + 2)) tuples <<= 1;   /* a tuple set of tree edges: at most n - 1 */
   uint64_t chain = 8; while (chain <= 8ull * (uint64_t)(2 * m + 2)) chain <<= 1;  /* the first one: the closure paths' edges, at most 2m */
-  return (uint64_t)T * (uint64_t)n * 2 + (uint64_t)T * (uint64_t)T * 8 + pairs * 20 + (uint64_t)(2 * m + 2) * 18 + (chain + 2 * tuples) * 24 + (uint64_t)n * 264 + 8192;
+  const uint64_t bytes = (uint64_t)T * (uint64_t)n * 2 + (uint64_t)T * (uint64_t)T * 8 + pairs * 20 + (uint64_t)(2 * m + 2) * 18 + (chain + 2 * tuples) * 24 + (uint64_t)n * 264 + 8192;
+  return (bytes + 15u) & ~(uint64_t)15u;  /* slot blocks follow one another: keep them aligned */
 }
 
 /* the value; *err = 1 when the arena was too small */

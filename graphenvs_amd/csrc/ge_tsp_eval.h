@@ -121,7 +121,7 @@ GE_KERNEL ge_k_mis_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slo
 // views, CPython's set tables for tuples and ints, float64 sum order).  One LANE per regenerated slot; replaces the own Kou-style
 // value the graph kernel left in heuristic[] (which stays if the work space were ever too small).
 GE_HOSTDEV uint64_t ge_steiner_slot_bytes(int n, int m, int T) {
-  return ((((uint64_t)(2 * m + 1) * 2) + 7) & ~7ull) + (uint64_t)(2 * m + 1) * 8 + ge_kou_arena_bytes(n, m, T);
+  return ((((uint64_t)(2 * m + 1) * 2) + 15) & ~15ull) + ((((uint64_t)(2 * m + 1) * 8) + 15) & ~15ull) + ge_kou_arena_bytes(n, m, T);
 }
 
 GE_KERNEL ge_k_steiner_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
@@ -133,11 +133,11 @@ GE_KERNEL ge_k_steiner_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t
     const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
     uint8_t *blk = scratch + (uint64_t)env * slot_bytes;
     uint16_t *adj = (uint16_t *)blk;
-    double *w = (double *)(blk + ((((uint64_t)(2 * P.m + 1) * 2) + 7) & ~7ull));
+    double *w = (double *)(blk + ((((uint64_t)(2 * P.m + 1) * 2) + 15) & ~15ull));
     const int64_t ebase = (int64_t)env * P.E;
     for (int k = 0; k < P.E; k++) { const uint16_t cw = G.colw[ebase + k]; adj[k] = (uint16_t)(cw >> 4); w[k] = ge_wlut(cw & 15); }
     ge_cr_arena a;
-    a.base = (uint8_t *)(w + (2 * P.m + 1)); a.top = 0; a.peak = 0; a.cap = ge_kou_arena_bytes(n, P.m, P.T); a.err = 0;
+    a.base = (uint8_t *)w + ((((uint64_t)(2 * P.m + 1) * 8) + 15) & ~15ull); a.top = 0; a.peak = 0; a.cap = ge_kou_arena_bytes(n, P.m, P.T); a.err = 0;
     ge_kou_in g;
     g.n = n; g.m = P.m; g.T = P.T; g.off = G.row_ptr + (int64_t)env * (n + 1); g.adj = adj; g.w = w; g.terms = G.terminals + (int64_t)env * P.T;
     int err = 0;
