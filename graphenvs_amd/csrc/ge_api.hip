@@ -2,6 +2,7 @@
 // kernel launches.  No device allocation, no synchronisation (except ge_timed_rollout).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -318,6 +319,9 @@ extern "C" int ge_destroy(ge_engine *e) {
 }
 
 static int check_launch(const char *what) {
+  // GE_DEBUG_SYNC=1: wait for every launch and name it (a kernel fault is otherwise reported at some later synchronisation)
+  static const bool debug_sync = getenv("GE_DEBUG_SYNC") != nullptr;
+  if (debug_sync) { fprintf(stderr, "[graphenvs] %s ...\n", what); fflush(stderr); (void)hipDeviceSynchronize(); fprintf(stderr, "[graphenvs] %s done\n", what); fflush(stderr); }
   hipError_t hr = hipGetLastError();
   if (hr != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(hr)); return GE_E_LAUNCH; }
   return GE_OK;
