@@ -29,6 +29,8 @@ GE_DEV unsigned char *ge_dyn_smem() {
   return ge_smem_raw;
 }
 GE_DEV void ge_sync() { __syncthreads(); }
+// issue priority of this wave among the waves of its SIMD (s_setprio, 0 = default .. 3)
+GE_DEV void ge_wave_priority(int p) { if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 // LDS hand-off between lanes of ONE wave (the other waves of the workgroup do not take part)
 GE_DEV void ge_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 // Ordering point between the four lanes of a quad that execute identical control flow: LDS operations of one wave

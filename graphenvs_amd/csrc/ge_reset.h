@@ -246,6 +246,12 @@ struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; co
 __device__ unsigned long long ge_stamp_buf[32];
 #define GE_STAMP(k) do { if (lane == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
 #define GE_STAMP_T0(k) do { if (tid == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
+#elif defined(GE_STAMP_SLOTS) && !defined(GE_EMU)
+// Diagnostic build only (-DGE_STAMP_SLOTS, never shipped; tools/slot_times.py): when every slot's regeneration starts (stamp 0), when
+// its graph is accepted (stamp 2) and when it is written (stamp 10), 100 MHz, into final_cost / final_len / final_heur of the slot --
+// the outputs of the step are garbage in such a build
+#define GE_STAMP(k) do { if (lane == 0) { if ((k) == 0) P.buf.final_cost[env] = (double)wall_clock64(); else if ((k) == 2) P.buf.final_len[env] = (int32_t)(wall_clock64() - (unsigned long long)P.buf.final_cost[env]); else if ((k) == 10) P.buf.final_heur[env] = (double)wall_clock64(); } } while (0)
+#define GE_STAMP_T0(k) do { } while (0)
 #else
 #define GE_STAMP(k) do { } while (0)
 #define GE_STAMP_T0(k) do { } while (0)
@@ -1087,7 +1093,12 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
         ok = ge_ppd_place(P, c, (double *)(ge_dyn_smem() + P.lds.fw), rnd, ppd_pos, ppd_pk, ppd_dp, ppd_dt, lane);
       }
       if (ok) break;
+      // a rejected attempt: from here on this wave is on the launch's critical path (tools/slot_times.py: the median slot is written
+      // 42 us after the launch starts, the slots that need three or four attempts after 70 us) -- let it win the issue arbitration
+      // against its eleven neighbours' waves (320.7 -> 316.7 us per headline step; raising the numpy wave as well gives it back)
+      ge_wave_priority(1);
     }
+    ge_wave_priority(0);
     if (failed) {  // flag it, and carry on with a valid graph (a path plus chords up to m edges) so that nothing downstream runs out of bounds
       if (lane == 0) atomicOr((unsigned int *)&P.buf.work_count[1], 1u);
       gen_failed = true;

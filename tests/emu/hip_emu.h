@@ -205,6 +205,7 @@ GE_DEV int ge_bdim() { return ge_emu::blk().nthreads; }
 GE_DEV int ge_gdim() { return ge_emu::blk().gdim; }
 GE_DEV unsigned char *ge_dyn_smem() { return ge_emu::blk().smem; }
 GE_DEV void ge_sync() { ge_emu::barrier(); }
+GE_DEV void ge_wave_priority(int) {}
 GE_DEV void ge_wave_sync() { ge_emu::wave_rendezvous(0); }
 GE_DEV void ge_quad_sync() { ge_emu::Block &b = ge_emu::blk(); b.fib[b.cur].waiting = 3; ge_emu::yield_to_sched(); }
 
