@@ -715,13 +715,14 @@ static void compute_mask(oge_env *e) {
   }
 }
 
-/* ------------------------------------------------------------------ own baselines
- * The reference's heavy baselines (networkx Kou Steiner tree, Christofides tour, clique-removal independent set) are
- * heuristics whose exact output depends on dict / set iteration orders deep inside networkx; SURVEY 8(f)-3 asks for
- * validity and bound checks, not bit parity.  The three functions below are this project's own deterministic
- * heuristics with the same guarantees (2-approximate Steiner tree, 2-approximate closed walk, maximal independent
- * set); the HIP engine implements exactly the same steps and is compared with them bit for bit, and they are compared
- * with the reference's values through bounds (tests/test_oracle_golden.py). */
+/* ------------------------------------------------------------------ baselines, fallbacks of round 1
+ * The reference's heavy baselines (networkx Kou Steiner tree, Christofides tour, clique-removal independent set) depend on
+ * dict / set iteration orders deep inside networkx.  The Kou tree and the clique removal are restated exactly (with those orders:
+ * graphenvs_amd/csrc/ge_kou_exact.h, ge_clique_removal.h, included further up); the TSP baseline is an own Christofides tour
+ * (ge_christofides.h), bound-checked.  The two functions below are round 1's own heuristics of the same kind (min-degree greedy
+ * maximal independent set, Kou-style 2-approximate Steiner tree): they remain the values reported should the exact restatements'
+ * work space ever be too small, the HIP engine implements exactly the same steps, and their validity and bounds are tested
+ * (tests/test_oracle_golden.py). */
 
 /* maximal independent set, min-degree greedy: repeatedly take the remaining node of smallest remaining degree (lowest
  * index on ties) and delete it with its neighbours.  Returns the size; `out` (n flags, may be NULL) receives the set. */
@@ -1346,7 +1347,7 @@ int oge_head(const oge_env *e) { return e->head; }
 int oge_num_targets(const oge_env *e) { return e->n_targets; }
 void oge_get_terminals(const oge_env *e, int32_t *out) { for (int i = 0; i <= e->n_targets; i++) out[i] = e->terms[i]; }
 
-/* test hooks: the objects behind the own baselines, recomputed on the current graph (oge_reset must have run) */
+/* test hooks: the objects behind the fallback heuristics, recomputed on the current graph (oge_reset must have run) */
 double oge_debug_greedy_mis(oge_env *e, uint8_t *out_n) { return greedy_mis_size(e, out_n); }
 double oge_debug_steiner_tree(oge_env *e, uint8_t *out_nn) { return kou_style_steiner(e, out_nn); }
 

@@ -7,7 +7,8 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  * The product (graphenvs_amd/, libgraphenvs_hip.so) never links, imports or calls it.
  *
- * Parity status: PINNED (except the three own baselines, see ge_oracle.c "own baselines": bound-checked) -- oracle/gen_golden.py runs the real reference in the build
+ * Parity status: PINNED (one exception, the TSP baseline: an own Christofides tour, bound-checked; networkx's Kou tree and clique removal
+ * are restated exactly, see ge_oracle.c "baselines") -- oracle/gen_golden.py runs the real reference in the build
  * container and tests/test_oracle_golden.py checks this file against those fixtures
  * (tests/golden/*.npz) and against the known answers of SURVEY.md section 10.
  */
@@ -69,7 +70,7 @@ void oge_get_obs(const oge_env *e, float *obs);               /* vectorize_graph
 void oge_get_mask(const oge_env *e, uint8_t *mask);           /* info['mask'] as of the last reset/step */
 void oge_get_features64(const oge_env *e, double *sf);        /* [n,5] float64 features before the f32 cast */
 double oge_solution_cost(const oge_env *e);
-double oge_heuristic_solution(const oge_env *e);              /* NaN if the baseline is not restated (Kou, Christofides, greedy MIS) */
+double oge_heuristic_solution(const oge_env *e);              /* info['heuristic_solution'] of the current episode */
 int oge_head(const oge_env *e);
 void oge_get_terminals(const oge_env *e, int32_t *out);       /* [0]=src, [1..] = dest(s); count = 1 + n_targets */
 int oge_num_targets(const oge_env *e);
