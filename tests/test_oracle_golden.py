@@ -224,6 +224,20 @@ def test_steiner_env_baseline_equals_networkx_on_the_env_graph(seed):
 
 
 @pytest.mark.parametrize("seed", range(3))
+def test_own_greedy_mis_fallback_is_a_maximal_independent_set(seed):
+    """the min-degree greedy set of round 1 stays as the value reported if the clique-removal restatement's work space were too small"""
+    import itertools
+    env = oracle.OracleEnv("MaxIndependentSet-v0", n_nodes=12, n_edges=20, weighted=False, is_eval_env=True)
+    env.reset(seed=seed)
+    size, member = env.debug_greedy_mis()
+    G = _nx_graph(env)
+    S = set(np.nonzero(member)[0].tolist())
+    assert size == len(S)
+    assert not any(G.has_edge(u, v) for u, v in itertools.combinations(S, 2))            # independent
+    assert all(any(G.has_edge(v, u) for u in S) for v in G if v not in S)                 # maximal
+
+
+@pytest.mark.parametrize("seed", range(3))
 def test_own_steiner_fallback_is_a_tree_over_the_terminals_within_twice_the_optimum(seed):
     """the Kou-style tree of round 1 stays as the value reported if the exact restatement's work space were ever too small"""
     import itertools
