@@ -61,11 +61,22 @@ class GeBuffers(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in BUFFER_FIELDS]
 
 
+class GeSpares(C.Structure):
+    """ge_spares of include/graphenvs.h: the spare image of every slot and the queues of the episode prefetch"""
+    _fields_ = [("image", GeBuffers), ("state", C.c_void_p), ("swap_list", C.c_void_p), ("swap_count", C.c_void_p),
+                ("refill_list", C.c_void_p), ("refill_count", C.c_void_p), ("period", C.c_int32)]
+
+
+# the per-slot slabs a spare image holds (the rest of ge_buffers sequences the engine and is shared with the live slabs)
+IMAGE_FIELDS = ["x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw64", "adj_bits", "node_rec", "rev_edge", "slot_rec",
+                "terminals", "node_bits", "target_bits", "counters", "heuristic", "aux_bits", "mask", "mask_bits", "node_aux",
+                "range_bits", "cover_bits"]
+
 # every symbol include/graphenvs.h declares
 SYMBOLS = [
     "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_ragged_table_bytes", "ge_create_ragged", "ge_reset", "ge_step", "ge_step_only",
     "ge_reset_pending", "ge_reset_continue", "ge_inject_state", "ge_mark_restored", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
-    "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash",
+    "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash", "ge_attach_spares",
 ]
 
 
@@ -112,12 +123,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and built_hash() == source_hash():
         last_build = "reused"
         return LIB_PATH
-    cmd = compile_command(LIB_PATH + ".tmp")
+    tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())  # per process: ranks that all find a stale library must not write one file
+    cmd = compile_command(tmp)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL,
                           stderr=None if verbose else subprocess.DEVNULL)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)  # a new inode: a process that already mapped the old file keeps the old one
+    os.replace(tmp, LIB_PATH)  # atomic, a new inode: a process that already mapped the old file keeps the old one
     last_build = "compiled"
     _lib = None
     return LIB_PATH
@@ -138,6 +150,8 @@ def bind(lib):
     lib.ge_ragged_table_bytes.argtypes = [i32]
     lib.ge_create_ragged.restype = C.c_int
     lib.ge_create_ragged.argtypes = [C.POINTER(GeConfig), C.POINTER(GeBuffers), i32, vp, vp, vp, C.POINTER(vp)]
+    lib.ge_attach_spares.restype = C.c_int
+    lib.ge_attach_spares.argtypes = [vp, C.POINTER(GeSpares), vp]
     lib.ge_reset.restype = C.c_int
     lib.ge_reset.argtypes = [vp, vp, vp]
     for name in ("ge_step", "ge_step_only"):
@@ -172,7 +186,7 @@ def bind(lib):
 _lib = None
 
 
-ABI_VERSION = 3  # GE_ABI_VERSION of include/graphenvs.h this host was written against
+ABI_VERSION = 4  # GE_ABI_VERSION of include/graphenvs.h this host was written against
 
 
 def load():

@@ -14,6 +14,7 @@
 #include "ge_features.h"
 #include "ge_step.h"
 #include "ge_tsp_eval.h"
+#include "ge_spare.h"
 
 struct ge_engine {
   GeParams P;
@@ -33,7 +34,28 @@ struct ge_engine {
   bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
   bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
   bool streams;   // stream_state holds the streams a regeneration left behind (ge_reset; a restored snapshot)
+  // episode prefetch (ge_attach_spares): PS is the engine seen through its spare image -- the same geometry, generator ring,
+  // seed[] / episode[] and work lists, but every per-slot slab is the image's and the queue is the refill list
+  bool spares;
+  GeParams PS;
+  GeRagged RS;                     // multi-class engine: class table whose bufs are the images
+  std::vector<GeParams> classesS;  // its host copy
+  int period, swap_parts;
+  int64_t pending_calls;           // ge_reset_pending calls since the last refill
+  int32_t *refill_list, *refill_count;
 };
+
+// ---- what a reset-path launch does (GeRun, ge_params.h): the only places where a request becomes flags
+static GeRun run_full() { GeRun r = {GE_ITEMS_ALL, 1, 0, 0, 0, 0, 0}; return r; }                         // ge_reset
+static GeRun run_inject(bool seeds) { GeRun r = {GE_ITEMS_ALL, seeds ? 2 : 0, 0, 0, 1, 0, 0}; return r; }  // ge_inject_state
+static GeRun run_continue() { GeRun r = {GE_ITEMS_ALL, 0, 1, 1, 0, 0, 0}; return r; }                     // ge_reset_continue
+// finished slots regenerated in place.  Without spares the launch that moves a slot to episode e + 1 refills ring entry e with
+// episode e + GE_SEED_DEPTH; with spares every regeneration of a slot -- refill or in place -- seeds the episode after the one it
+// generates, two past the one seed[] / episode[] name
+static GeRun run_queue(const ge_engine *e) { GeRun r = {GE_ITEMS_QUEUE, 0, 1, 0, 0, 0, e->spares ? 2 : GE_SEED_DEPTH}; return r; }
+static GeRun run_refill() { GeRun r = {GE_ITEMS_QUEUE, 0, 1, 0, 0, 1, 2}; return r; }
+static GeRun as_list(GeRun r) { r.items = GE_ITEMS_LIST; return r; }  // the feature kernels' fallback list of the same launch sequence
+
 
 static thread_local char g_err[256] = "";
 static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
@@ -256,6 +278,7 @@ extern "C" int ge_create(const ge_config *cfg, const ge_buffers *bufs, ge_engine
   if (!e) return fail(GE_E_BADARG, "out of host memory");
   e->P = P; e->cfg = *cfg; e->have_events = false;
   e->loaded = false; e->seeded = false; e->streams = false;
+  e->spares = false; e->period = 0; e->swap_parts = 1; e->pending_calls = 0; memset(&e->RS, 0, sizeof(e->RS));
   e->n_classes = 0; memset(&e->R, 0, sizeof(e->R));
   return finish_create(e, out);
 }
@@ -270,6 +293,8 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
     return fail(GE_E_UNSUPPORTED, "the multi-class engine is built for ShortestPath, DensestSubgraph and MaxIndependentSet (BASELINE config 5)");
   int64_t total = 0;
   for (int c = 0; c < n_classes; c++) total += cfgs[c].num_envs;
+  if (cfgs[0].is_eval_env && t == GE_MAX_INDEPENDENT_SET && !cfgs[0].weighted)
+    return fail(GE_E_UNSUPPORTED, "is_eval_env of unweighted MaxIndependentSet (the clique-removal baseline, a launch per uniform engine) is not built for the multi-class engine");
   if (total > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
   ge_engine *e = new (std::nothrow) ge_engine();
   if (!e) return fail(GE_E_BADARG, "out of host memory");
@@ -301,6 +326,7 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
   e->P.env_index_base = cfgs[0].env_index_base;
   e->cfg = cfgs[0]; e->cfg.num_envs = (int32_t)total;
   e->have_events = false; e->loaded = false; e->seeded = false; e->streams = false;
+  e->spares = false; e->period = 0; e->swap_parts = 1; e->pending_calls = 0; memset(&e->RS, 0, sizeof(e->RS));
   e->n_classes = n_classes;
   if (hipMemcpy(class_table, e->classes.data(), sizeof(GeParams) * (size_t)n_classes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(slot_class, cls_of.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice) != hipSuccess ||
@@ -309,6 +335,66 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
   }
   e->R.classes = (const GeParams *)class_table; e->R.slot_class = slot_class; e->R.class_start = class_start; e->R.n_classes = n_classes;
   return finish_create(e, out);
+}
+
+// the per-slot slabs an image must hold for this (sub-)engine
+static int check_image(const GeParams &P, const ge_buffers &I) {
+  const void *need[] = {I.x, I.edge_index, I.edge_attr, I.row_ptr, I.colw, I.scode, I.adj_bits, I.slot_rec, I.terminals, I.node_bits,
+                        I.target_bits, I.counters, I.heuristic, I.mask, I.mask_bits};
+  for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); k++) if (!need[k]) return fail(GE_E_BADARG, "a required slab of the spare image is null");
+  const ge_buffers &G = P.buf;
+  if ((G.sw64 && !I.sw64) || (G.node_rec && !I.node_rec) || (G.rev_edge && !I.rev_edge) || (G.aux_bits && !I.aux_bits) || (G.node_aux && !I.node_aux) ||
+      (G.range_bits && !I.range_bits) || (G.cover_bits && !I.cover_bits))
+    return fail(GE_E_BADARG, "the spare image lacks an optional slab the engine has (sw64 / node_rec / rev_edge / aux_bits / node_aux / range_bits / cover_bits)");
+  return GE_OK;
+}
+// V = P seen through image I: per-slot slabs from the image, everything that sequences the engine shared with the live view
+static GeParams image_view(const GeParams &P, const ge_buffers &I, int32_t *refill_list, int32_t *refill_count) {
+  GeParams V = P;
+  ge_buffers B = I;
+  const ge_buffers &G = P.buf;
+  B.seed = G.seed; B.episode = G.episode; B.mt_state = G.mt_state;
+  B.work_list = G.work_list; B.work_count = G.work_count; B.feat_scratch = G.feat_scratch; B.eval_scratch = G.eval_scratch;
+  B.reset_list = refill_list; B.reset_count = refill_count;
+  B.reward = G.reward; B.terminated = G.terminated; B.invalid = G.invalid; B.solved = G.solved;
+  B.final_cost = G.final_cost; B.final_heur = G.final_heur; B.final_len = G.final_len;  // (not written by a refill)
+  B.actions_out = nullptr; B.stream_state = nullptr;
+  V.buf = B;
+  return V;
+}
+
+extern "C" int ge_attach_spares(ge_engine *e, const ge_spares *sp, void *class_table_spare) {
+  if (!e || !sp) return fail(GE_E_BADARG, "null argument");
+  if (e->spares) return fail(GE_E_STATE, "spares are already attached");
+  if (!e->P.autoreset) return fail(GE_E_BADARG, "spares serve autoreset: this engine freezes finished slots");
+  if (e->P.buf.stream_state) return fail(GE_E_UNSUPPORTED, "spares and stream_state (reset(seed=None) continuing the streams) exclude each other: an image generated ahead of time would leave the streams of the wrong episode behind");
+  if (!sp[0].state || !sp[0].swap_list || !sp[0].swap_count || !sp[0].refill_list || !sp[0].refill_count) return fail(GE_E_BADARG, "state / swap_list / swap_count / refill_list / refill_count are required");
+  if (sp[0].period < 1) return fail(GE_E_BADARG, "period must be >= 1");
+  if (e->n_classes > 0 && !class_table_spare) return fail(GE_E_BADARG, "a multi-class engine needs class_table_spare (ge_ragged_table_bytes)");
+  int rc = GE_OK;
+  if (e->n_classes == 0) rc = check_image(e->P, sp[0].image);
+  for (int c = 0; c < e->n_classes && rc == GE_OK; c++) rc = check_image(e->classes[c], sp[c].image);
+  if (rc != GE_OK) return rc;
+  e->refill_list = sp[0].refill_list; e->refill_count = sp[0].refill_count;
+  e->PS = image_view(e->P, sp[0].image, e->refill_list, e->refill_count);
+  if (e->n_classes > 0) {
+    e->classesS.resize(e->n_classes);
+    for (int c = 0; c < e->n_classes; c++) e->classesS[c] = image_view(e->classes[c], sp[c].image, e->refill_list, e->refill_count);
+    if (hipMemcpy(class_table_spare, e->classesS.data(), sizeof(GeParams) * (size_t)e->n_classes, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(GE_E_LAUNCH, "cannot copy the spare class table to the device");
+    e->RS = e->R; e->RS.classes = (const GeParams *)class_table_spare;
+  }
+  e->P.spare_state = sp[0].state; e->P.swap_list = sp[0].swap_list; e->P.swap_count = sp[0].swap_count;
+  e->PS.spare_state = sp[0].state;
+  e->period = sp[0].period; e->pending_calls = 0;
+  // a slot's image is some tens of KB: split it over workgroups so that a handful of finished slots is not a handful of workgroups
+  const GeParams &P = e->P;
+  const int64_t slot_bytes = (int64_t)P.n * P.F * 4 + (int64_t)P.E * (16 + 4 * P.Fe + 2 + 1 + (P.buf.rev_edge ? 4 : 0)) + (int64_t)P.n * P.W * 8 * (P.buf.range_bits ? 2 : 1) + P.A;
+  int parts = (int)(slot_bytes / 8192); if (parts < 1) parts = 1; if (parts > 16) parts = 16;
+  e->swap_parts = parts;
+  e->spares = true;
+  // (the caller zeroes `state`; ge_reset / ge_inject_state clear it and refill every image)
+  return GE_OK;
 }
 
 extern "C" int ge_destroy(ge_engine *e) {
@@ -321,7 +407,12 @@ extern "C" int ge_destroy(ge_engine *e) {
 static int check_launch(const char *what) {
   // GE_DEBUG_SYNC=1: wait for every launch and name it (a kernel fault is otherwise reported at some later synchronisation)
   static const bool debug_sync = getenv("GE_DEBUG_SYNC") != nullptr;
-  if (debug_sync) { fprintf(stderr, "[graphenvs] %s ...\n", what); fflush(stderr); (void)hipDeviceSynchronize(); fprintf(stderr, "[graphenvs] %s done\n", what); fflush(stderr); }
+  if (debug_sync) {
+    fprintf(stderr, "[graphenvs] %s ...\n", what); fflush(stderr);
+    const hipError_t hs = hipDeviceSynchronize();  // an asynchronous fault of THIS launch surfaces here
+    fprintf(stderr, "[graphenvs] %s %s\n", what, hs == hipSuccess ? "done" : hipGetErrorString(hs)); fflush(stderr);
+    if (hs != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s (GE_DEBUG_SYNC)", what, hipGetErrorString(hs)); return GE_E_LAUNCH; }
+  }
   hipError_t hr = hipGetLastError();
   if (hr != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(hr)); return GE_E_LAUNCH; }
   return GE_OK;
@@ -336,101 +427,126 @@ static int launch_seed(ge_engine *e, const uint32_t *seeds, int jlo, void *strea
   return check_launch("seed kernel");
 }
 
-static int launch_combine(ge_engine *e, int mode, void *stream) {
+// V: the engine (e->P) or its spare-image view (e->PS); VR: the matching class table
+static int launch_combine(ge_engine *e, const GeParams &V, const GeRagged &VR, GeRun run, void *stream) {
   const bool rg = e->n_classes > 0;
-  size_t lds = (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
-  int64_t items = (int64_t)(mode == GE_RESET_ALL ? e->P.B : 4096) * e->P.n;
+  size_t lds = (size_t)((V.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
+  int64_t items = (int64_t)(run.items == GE_ITEMS_ALL ? V.B : 4096) * V.n;
   int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
-  if (rg) GE_LAUNCH(ge_k_feat_combine<true>, grid, 256, lds, stream, e->P, e->R, mode);
-  else GE_LAUNCH(ge_k_feat_combine<false>, grid, 256, lds, stream, e->P, e->R, mode);
+  if (rg) GE_LAUNCH(ge_k_feat_combine<true>, grid, 256, lds, stream, V, VR, run);
+  else GE_LAUNCH(ge_k_feat_combine<false>, grid, 256, lds, stream, V, VR, run);
   return check_launch("feature combine kernel");
 }
 
-static int launch_features(ge_engine *e, int mode, void *stream) {
+// `small`: the queue is expected to be short (the in-place regenerations of an engine with spares): a fraction of the grid
+static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, GeRun run, bool small, void *stream) {
   int rc = GE_OK;
-  const bool rg = e->n_classes > 0;
-  int fgrid = (mode == GE_RESET_QUEUE) ? e->feat_grid : (e->P.B < e->feat_grid * 4 ? e->P.B : e->feat_grid * 4);
-  const int gen_threads = GE_WAVE * (rg ? e->classes[0].ldsf.waves : e->P.ldsf.waves);
+  const bool rg = e->n_classes > 0, queue = run.items == GE_ITEMS_QUEUE;
+  int fgrid = queue ? e->feat_grid : (V.B < e->feat_grid * 4 ? V.B : e->feat_grid * 4);
+  if (small && fgrid > 256) fgrid = 256;
+  const int gen_threads = GE_WAVE * (rg ? e->classes[0].ldsf.waves : V.ldsf.waves);
   if (e->feat_fast) {
-    if (rg) GE_LAUNCH(ge_k_features64<true>, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, e->R, mode, e->feat64_pre_off);
-    else GE_LAUNCH(ge_k_features64<false>, fgrid, GE_F64_THREADS, e->feat_lds, stream, e->P, e->R, mode, e->feat64_pre_off);
+    if (rg) GE_LAUNCH(ge_k_features64<true>, fgrid, GE_F64_THREADS, e->feat_lds, stream, V, VR, run, e->feat64_pre_off);
+    else GE_LAUNCH(ge_k_features64<false>, fgrid, GE_F64_THREADS, e->feat_lds, stream, V, VR, run, e->feat64_pre_off);
     rc = check_launch("feature kernel (n <= 64)");
     if (rc != GE_OK) return rc;
     // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64, feat_parts workgroups each
     if (rg) {
-      int64_t want = (int64_t)e->gen_grid * ge_feat_workgroups(e->P.feat_parts) * (mode == GE_RESET_QUEUE ? 1 : 4);
+      int64_t want = (int64_t)e->gen_grid * ge_feat_workgroups(V.feat_parts) * (queue ? 1 : 4);
+      if (small && want > 1024) want = 1024;
       if (want > 65535 * 16) want = 65535 * 16;
-      GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
+      GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off);
       rc = check_launch("feature kernel (list)");
-      return (rc == GE_OK && e->P.feat_parts > 1) ? launch_combine(e, GE_FEAT_LIST, stream) : rc;
+      return (rc == GE_OK && V.feat_parts > 1) ? launch_combine(e, V, VR, as_list(run), stream) : rc;
     }
     int g2 = e->gen_grid < 64 ? e->gen_grid : 64;
-    GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, e->P, e->R, (int)GE_FEAT_LIST, e->gen_pre_off);
+    GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off);
     return check_launch("feature kernel (fallback list)");
   }
   {
-    int64_t want = (int64_t)fgrid * ge_feat_workgroups(e->P.feat_parts);
-    if (mode == GE_RESET_QUEUE && want > 4608) want = 4608;  // queue mode: the list is short, workgroups stride over it
+    int64_t want = (int64_t)fgrid * ge_feat_workgroups(V.feat_parts);
+    if (queue && !run.refill && want > 4608) want = 4608;  // the list is short, workgroups stride over it
+    if (small && want > 1152) want = 1152;
     if (want > 65535 * 16) want = 65535 * 16;
-    if (rg) GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);
-    else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, e->P, e->R, mode, e->gen_pre_off);
+    if (rg) GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off);
+    else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off);
   }
   rc = check_launch("feature kernel");
-  if (rc != GE_OK || e->P.feat_parts == 1) return rc;
-  return launch_combine(e, mode, stream);
+  if (rc != GE_OK || V.feat_parts == 1) return rc;
+  return launch_combine(e, V, VR, run, stream);
 }
 
 // is_eval_env baselines that are sequential programs (ge_tsp_eval.h: TSP Christofides, MaxIndependentSet clique removal) for the
 // regenerated slots, on the slabs the graph kernel wrote
-static int launch_seq_baseline(ge_engine *e, int mode, void *stream) {
-  const GeParams &P = e->P;
+static int launch_seq_baseline(ge_engine *e, const GeParams &P, int queue, void *stream) {
   const uint64_t slot_bytes = eval_slot_bytes(P);
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  (void)e;
   if (P.env_type == GE_MAX_INDEPENDENT_SET) {
     int g = (P.B + GE_TSP_EVAL_THREADS - 1) / GE_TSP_EVAL_THREADS; if (g > 4096) g = 4096;
-    GE_LAUNCH(ge_k_mis_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes);
+    GE_LAUNCH(ge_k_mis_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, queue, (uint8_t *)P.buf.eval_scratch, slot_bytes);
     return check_launch("MaxIndependentSet baseline kernel");
   }
   if (P.env_type == GE_STEINER_TREE) {
     int g = (P.B + GE_TSP_EVAL_THREADS - 1) / GE_TSP_EVAL_THREADS; if (g > 4096) g = 4096;
-    GE_LAUNCH(ge_k_steiner_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes);
+    GE_LAUNCH(ge_k_steiner_baseline, g, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, queue, (uint8_t *)P.buf.eval_scratch, slot_bytes);
     return check_launch("SteinerTree baseline kernel");
   }
   const int pre_off = GE_WAVE * P.W * 8;
   int grid = P.B < 2048 ? P.B : 2048;
-  GE_LAUNCH(ge_k_tsp_closure, grid, GE_TSP_EVAL_THREADS, pre_off + (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes, pre_off);
+  GE_LAUNCH(ge_k_tsp_closure, grid, GE_TSP_EVAL_THREADS, pre_off + (nblk + 2) * 4, stream, P, queue, (uint8_t *)P.buf.eval_scratch, slot_bytes, pre_off);
   int rc = check_launch("TSP baseline: closure kernel");
   if (rc != GE_OK) return rc;
   grid = (P.B + GE_TSP_EVAL_THREADS - 1) / GE_TSP_EVAL_THREADS; if (grid > 4096) grid = 4096;
-  GE_LAUNCH(ge_k_tsp_tour, grid, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, mode, (uint8_t *)P.buf.eval_scratch, slot_bytes);
+  GE_LAUNCH(ge_k_tsp_tour, grid, GE_TSP_EVAL_THREADS, (nblk + 2) * 4, stream, P, queue, (uint8_t *)P.buf.eval_scratch, slot_bytes);
   return check_launch("TSP baseline: tour kernel");
 }
 
-// mode GE_RESET_ALL / GE_RESET_INJECT: every slot; GE_RESET_QUEUE: the slots the last step launch queued.  Everything on the
-// caller's stream, in order: generator states (full reset: the ring of every slot; queue mode: seeding workgroups inside the
-// reset launch), graph kernel, feature kernel(s).
-static int launch_reset(ge_engine *e, const uint32_t *seeds, int mode, const GeInject &inj, void *stream) {
+// One pass of the reset path over the items `run` names, on the engine (V = e->P) or on its spare image (V = e->PS, run.refill).
+// Everything on the caller's stream, in order: generator states (full reset: the ring of every slot; queue launches: seeding
+// workgroups inside the reset launch), graph kernel, sequential baselines, feature kernel(s).
+static int launch_reset(ge_engine *e, const GeParams &V, const GeRagged &VR, const uint32_t *seeds, GeRun run, const GeInject &inj, bool small, void *stream) {
   int rc = GE_OK;
-  if (mode == GE_RESET_ALL) rc = launch_seed(e, seeds, 0, stream);
-  else if (mode == GE_RESET_INJECT && inj.seeds) rc = launch_seed(e, inj.seeds, 1, stream);  // the injected episode needs no states of its own
+  const bool queue = run.items == GE_ITEMS_QUEUE;
+  if (run.restart == 1) rc = launch_seed(e, seeds, 0, stream);
+  else if (run.restart == 2) rc = launch_seed(e, inj.seeds, 1, stream);  // the injected episode needs no states of its own
   if (rc != GE_OK) return rc;
-  if (mode == GE_RESET_CONT) {
-    int64_t g = ((int64_t)e->P.B + GE_WAVE - 1) / GE_WAVE; if (g > 8192) g = 8192;
-    GE_LAUNCH(ge_k_seed_next, (int)g, 2 * GE_WAVE, GE_SEED_LDS_BYTES, stream, e->P);
+  if (run.cont) {
+    int64_t g = ((int64_t)V.B + GE_WAVE - 1) / GE_WAVE; if (g > 8192) g = 8192;
+    GE_LAUNCH(ge_k_seed_next, (int)g, 2 * GE_WAVE, GE_SEED_LDS_BYTES, stream, V);
     rc = check_launch("seed kernel (next ring entry)");
     if (rc != GE_OK) return rc;
   }
-  int grid = (mode == GE_RESET_QUEUE) ? e->reset_grid + e->nseed : (e->P.B < e->reset_grid * 4 ? e->P.B : e->reset_grid * 4);
-  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
-  else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, e->P, e->R, seeds, mode, inj, e->nseed));
+  int rgrid = e->reset_grid, nseed = e->nseed;
+  if (small && rgrid > 512) { rgrid = 512; nseed = 8; }
+  if (!queue) nseed = 0;
+  const int grid = queue ? rgrid + nseed : (V.B < e->reset_grid * 4 ? V.B : e->reset_grid * 4);
+  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed));
+  else GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed));
   rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;
-  if (mode != GE_RESET_INJECT && e->n_classes == 0 && eval_slot_bytes(e->P)) rc = launch_seq_baseline(e, mode == GE_RESET_QUEUE ? mode : (int)GE_RESET_ALL, stream);
+  if (!run.inject && e->n_classes == 0 && eval_slot_bytes(V)) rc = launch_seq_baseline(e, V, queue ? 1 : 0, stream);
   if (rc != GE_OK) return rc;
-  if (mode != GE_RESET_INJECT) rc = launch_features(e, mode == GE_RESET_CONT ? (int)GE_RESET_ALL : mode, stream);
-  if (rc == GE_OK && (mode == GE_RESET_ALL || inj.seeds)) e->seeded = true;
-  if (rc == GE_OK && mode == GE_RESET_ALL && e->P.buf.stream_state) e->streams = true;
+  if (!run.inject) rc = launch_features(e, V, VR, run, small, stream);
+  if (rc == GE_OK && run.restart) e->seeded = true;
+  if (rc == GE_OK && run.restart == 1 && e->P.buf.stream_state) e->streams = true;
   return rc;
+}
+
+// every image is empty; with seeded generator states refill them all right away (one pass at full occupancy)
+static int refill_spares(ge_engine *e, void *stream) {
+  const int nblk = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  GE_LAUNCH(ge_k_refill_list, nblk, GE_STEP_BLOCK, 64, stream, e->P, e->refill_list, e->refill_count);
+  int rc = check_launch("refill list kernel");
+  if (rc != GE_OK) return rc;
+  GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  e->pending_calls = 0;
+  return launch_reset(e, e->PS, e->RS, nullptr, run_refill(), none, false, stream);
+}
+static int invalidate_spares(ge_engine *e, void *stream) {
+  if (!e->spares) return GE_OK;
+  if (hipMemsetAsync(e->P.spare_state, 0, (size_t)e->P.B, (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
+  return (e->seeded && e->P.autoreset) ? refill_spares(e, stream) : GE_OK;
 }
 
 static int clear_queue(ge_engine *e, void *stream) {  // a full reset / injection leaves the finished-slot queue empty
@@ -444,20 +560,22 @@ extern "C" int ge_reset(ge_engine *e, const uint32_t *seeds, void *stream) {
   GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int rc = clear_queue(e, stream);
   if (rc != GE_OK) return rc;
-  rc = launch_reset(e, seeds, GE_RESET_ALL, none, stream);
+  rc = launch_reset(e, e->P, e->R, seeds, run_full(), none, false, stream);
   if (rc == GE_OK) e->loaded = true;
+  if (rc == GE_OK) rc = invalidate_spares(e, stream);  // ... and refill: every slot's episode 1 waits in its image
   return rc;
 }
 
 extern "C" int ge_reset_continue(ge_engine *e, void *stream) {
   if (!e) return fail(GE_E_BADARG, "null argument");
   if (e->n_classes > 0) return fail(GE_E_UNSUPPORTED, "ge_reset_continue is not built for the multi-class engine");
+  if (e->spares) return fail(GE_E_UNSUPPORTED, "ge_reset_continue on an engine with spares: an image generated ahead of time would leave the streams of the wrong episode behind");
   if (!e->P.buf.stream_state) return fail(GE_E_STATE, "ge_reset_continue needs ge_buffers.stream_state (the streams every reset leaves behind)");
   if (!e->loaded || !e->seeded || !e->streams) return fail(GE_E_STATE, "ge_reset_continue before ge_reset: there is no stream to continue");
   GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int rc = clear_queue(e, stream);
   if (rc != GE_OK) return rc;
-  return launch_reset(e, nullptr, GE_RESET_CONT, none, stream);
+  return launch_reset(e, e->P, e->R, nullptr, run_continue(), none, false, stream);
 }
 
 extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t *wcode, const float *x,
@@ -473,8 +591,9 @@ extern "C" int ge_inject_state(ge_engine *e, const int64_t *links, const uint8_t
   GeInject inj = {links, wcode, x, terminals, seeds};
   int rc = clear_queue(e, stream);  // slots queued before the injection must not be regenerated over the injected state
   if (rc != GE_OK) return rc;
-  rc = launch_reset(e, nullptr, GE_RESET_INJECT, inj, stream);
+  rc = launch_reset(e, e->P, e->R, nullptr, run_inject(seeds != nullptr), inj, false, stream);
   if (rc == GE_OK) e->loaded = true;
+  if (rc == GE_OK) rc = invalidate_spares(e, stream);  // the images belong to the episodes that follow the injected ones
   return rc;
 }
 
@@ -544,7 +663,17 @@ extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
   if (rc != GE_OK) return rc;
   if (e->P.autoreset) {
     GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    rc = launch_reset(e, nullptr, GE_RESET_QUEUE, none, stream);
+    if (e->spares) {  // finished slots with a valid image: one streaming copy each
+      const int nblk = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+      int64_t grid = 2048 * (int64_t)(e->swap_parts > 4 ? 4 : e->swap_parts);
+      if (grid > (int64_t)e->P.B * e->swap_parts) grid = (int64_t)e->P.B * e->swap_parts;
+      if (e->n_classes > 0) GE_LAUNCH(ge_k_swap<true>, (int)grid, 256, (nblk + 2) * 4, stream, e->P, e->R, e->RS, e->PS.buf, e->swap_parts);
+      else GE_LAUNCH(ge_k_swap<false>, (int)grid, 256, (nblk + 2) * 4, stream, e->P, e->R, e->RS, e->PS.buf, e->swap_parts);
+      rc = check_launch("swap kernel");
+      if (rc != GE_OK) return rc;
+    }
+    rc = launch_reset(e, e->P, e->R, nullptr, run_queue(e), none, e->spares, stream);  // (with spares: the slots that finished again before their image was refilled)
+    if (rc == GE_OK && e->spares && ++e->pending_calls >= e->period) rc = refill_spares(e, stream);
   }
   return rc;
 }
@@ -565,6 +694,7 @@ extern "C" int ge_step(ge_engine *e, const int64_t *actions, void *stream) {
 extern "C" int ge_mark_restored(ge_engine *e) {
   if (!e) return GE_E_BADARG;
   e->loaded = true; e->seeded = true; e->streams = e->P.buf.stream_state != nullptr;
+  e->pending_calls = e->period;  // (the caller restores or clears spare_state with the other slabs; refill at the next opportunity)
   return GE_OK;
 }
 

@@ -456,30 +456,31 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   GE_STAMP(17);
 }
 
-enum { GE_FEAT_LIST = 3 };  // slots from work_list (fallback of the fast path)
 
 // the class of a global slot (multi-class engine), as a wave-uniform value
 GE_DEV int ge_slot_class(const GeRagged &R, int env) { return (int)ge_uniform_u32((uint32_t)R.slot_class[env]); }
 
-// mode GE_RESET_ALL: every slot; GE_RESET_QUEUE: the slots the last step kernel queued; GE_FEAT_LIST: work_list.  pre_off: byte
-// offset of the queue prefix inside the dynamic LDS (behind the largest class's scratch in a multi-class engine).
+// run.items GE_ITEMS_ALL: every slot; GE_ITEMS_QUEUE: the slots of P.buf.reset_list; GE_ITEMS_LIST: work_list (fallback of the
+// fast path).  pre_off: byte offset of the queue prefix inside the dynamic LDS (behind the largest class's scratch in a multi-class
+// engine).
 template <bool RAGGED>
-GE_KERNEL ge_k_features(GeParams P, GeRagged R, int mode, int pre_off) {
+GE_KERNEL ge_k_features(GeParams P, GeRagged R, GeRun run, int pre_off) {
   int *pre = (int *)(ge_dyn_smem() + pre_off);
-  int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
-  if (mode == GE_RESET_QUEUE) {
+  const bool queue = run.items == GE_ITEMS_QUEUE, list = run.items == GE_ITEMS_LIST;
+  int count = list ? P.buf.work_count[0] : P.B;
+  if (queue) {
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
   }
   // workgroups per item: the uniform engine's fallback list is rare and small (one workgroup each); the multi-class engine sends
   // every slot of a class with n > 64 through the list, feat_parts workgroups each (P.feat_parts = the largest class's)
-  const int fparts = (mode == GE_FEAT_LIST && !RAGGED) ? 1 : P.feat_parts;
+  const int fparts = (list && !RAGGED) ? 1 : P.feat_parts;
   const int nparts = ge_feat_workgroups(fparts);  // workgroups per item (engine-wide: the largest class's)
   for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
     const int item = q / nparts, part = q % nparts;
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
-    if (mode == GE_RESET_QUEUE && part == 0 && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
+    const int env = queue ? ge_queue_slot(P, pre, item) : (list ? P.buf.work_list[item] : item);
+    if (queue && part == 0 && ge_tid() == 0) ge_finish_item(P, run, env);  // seed[] / episode[] now name the new episode (refill: the image is valid)
     if constexpr (RAGGED) {
       const int cls = ge_slot_class(R, env);
       const GeParams &C = R.classes[cls];
@@ -493,10 +494,11 @@ GE_KERNEL ge_k_features(GeParams P, GeRagged R, int mode, int pre_off) {
 // betweenness of multi-part slots: parts added in part order, then the 1/((n-1)(n-2)) rescale and the float32 cast.  Multi-class
 // engine: items are (slot, node) over the widest class's n; a thread looks up its slot's class and skips what does not exist there.
 template <bool RAGGED>
-GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, int mode) {
+GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, GeRun run) {
   int *pre = (int *)ge_dyn_smem();
-  int count = (mode == GE_FEAT_LIST) ? P.buf.work_count[0] : P.B;
-  if (mode == GE_RESET_QUEUE) {
+  const bool queue = run.items == GE_ITEMS_QUEUE, list = run.items == GE_ITEMS_LIST;
+  int count = list ? P.buf.work_count[0] : P.B;
+  if (queue) {
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
@@ -504,7 +506,7 @@ GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, int mode) {
   const int nmax = P.n;
   for (int64_t g = (int64_t)ge_bid() * ge_bdim() + ge_tid(); g < (int64_t)count * nmax; g += (int64_t)ge_gdim() * ge_bdim()) {
     const int item = (int)(g / nmax), v = (int)(g % nmax);
-    int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, item) : (mode == GE_FEAT_LIST ? P.buf.work_list[item] : item);
+    int env = queue ? ge_queue_slot(P, pre, item) : (list ? P.buf.work_list[item] : item);
     int cls = 0;
     if constexpr (RAGGED) { cls = R.slot_class[env]; env -= R.class_start[cls]; }
     const GeParams &C = RAGGED ? R.classes[cls] : P;
@@ -519,18 +521,19 @@ GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, int mode) {
 
 // n <= 64 fast path over every slot / the queue.  Multi-class engine: a slot of a class with n > 64 goes straight to work_list.
 template <bool RAGGED>
-GE_KERNEL ge_k_features64(GeParams P, GeRagged R, int mode, int pre_off) {
+GE_KERNEL ge_k_features64(GeParams P, GeRagged R, GeRun run, int pre_off) {
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
   int *pre = (int *)(ge_dyn_smem() + pre_off);
+  const bool queue = run.items == GE_ITEMS_QUEUE;
   int count = P.B;
-  if (mode == GE_RESET_QUEUE) {  // the prefix scan is one wave wide
+  if (queue) {  // the prefix scan is one wave wide
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[nblk];
   }
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
-    if (mode == GE_RESET_QUEUE && ge_tid() == 0) ge_advance_episode(P, env);  // seed[] / episode[] now name the new episode
+    const int env = queue ? ge_queue_slot(P, pre, q) : q;
+    if (queue && ge_tid() == 0) ge_finish_item(P, run, env);  // seed[] / episode[] now name the new episode (refill: the image is valid)
     if constexpr (RAGGED) {
       const int cls = ge_slot_class(R, env);
       const GeParams &C = R.classes[cls];

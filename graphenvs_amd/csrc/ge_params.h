@@ -65,6 +65,27 @@ struct GeParams {
   ge_buffers buf;
   GeLds lds;
   GeLdsF ldsf;
+  // episode prefetch (ge_attach_spares; all NULL without it).  spare_state[slot] = 1: the slot's spare image holds its NEXT
+  // episode; the step kernels then queue a finished slot in swap_list / swap_count (same layout as reset_list / reset_count)
+  // instead of the regeneration queue, and a copy kernel moves the image in
+  uint8_t *spare_state;
+  int32_t *swap_list, *swap_count;
+};
+
+// What a launch of the reset path does.  Decoded ONCE, on the host, from a validated request (ge_api.hip: run_*), so that the
+// kernels test named flags instead of comparing a `mode` integer in two dozen places (a value outside the enum used to fall into
+// the full-reset branches of a queue launch -- profiles/README.md, "the aperture violation of round 2").
+enum { GE_ITEMS_ALL = 0, GE_ITEMS_QUEUE = 1, GE_ITEMS_LIST = 2 };
+struct GeRun {
+  int32_t items;       // GE_ITEMS_ALL: every slot; GE_ITEMS_QUEUE: P.buf.reset_list / reset_count; GE_ITEMS_LIST: work_list (feature kernels only)
+  int32_t restart;     // episode 0 of every item: 1 = seeded seeds[slot] (ge_reset), 2 = seeded inj.seeds[slot] (ge_inject_state with seeds)
+  int32_t next;        // the item moves to its next episode: seed + seed_stride, ring entry (episode + 1) % GE_SEED_DEPTH
+  int32_t cont;        // the two streams continue from stream_state instead of a pre-seeded ring entry (reset(seed=None))
+  int32_t inject;      // topology / weights / terminals / x are the caller's (GeInject), nothing is drawn
+  int32_t refill;      // P.buf is the SPARE image of the engine: the slot itself keeps running its episode -- no episode advance,
+                       // no final_heur, the slot's step count is not read; the feature kernel marks the image valid instead
+  int32_t seed_ahead;  // queue launches: seeding workgroups write the states of episode (e + seed_ahead), seeded seed[] + seed_ahead *
+                       // seed_stride, into ring entry (e + seed_ahead) % GE_SEED_DEPTH, e = episode[] of the item; 0 = none
 };
 
 // Multi-class ("ragged") engine, BASELINE config 5: slots of different (n, m) stepped by ONE launch sequence.  A size class is a

@@ -233,7 +233,6 @@ GE_DEV int ge_sorted_pos_p(const GeParams &P, const GeRctx &c, int u, int v) {
   return P.complete ? c.rowptr[u] + v - (v > u ? 1 : 0) : ge_sorted_pos(c, P.W, u, v);
 }
 
-enum { GE_RESET_ALL = 0, GE_RESET_QUEUE = 1, GE_RESET_INJECT = 2, GE_RESET_CONT = 3 };  // CONT: every slot, from the saved streams (reset(seed=None))
 
 struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; const int32_t *terminals; const uint32_t *seeds; };
 #ifndef GE_GNM_ROUND_CAP
@@ -937,7 +936,7 @@ GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, cons
 }
 
 template <int ENV>
-GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, int mode, const GeInject &inj) {
+GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, const GeRun &run, const GeInject &inj) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
   // Inside a wave only wave-level hand-offs are used; the two block barriers are the join and the end of the slot.
   const int tid = ge_tid_fresh();
@@ -953,31 +952,34 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   // seed / episode alone (the episodes that follow continue the earlier sequence).  In queue mode seed[] / episode[] still hold
   // the OLD episode while this kernel runs -- its seeding workgroups read them too -- and the feature kernel, the last kernel
   // of a regeneration, advances them (ge_advance_episode).
-  // GE_RESET_CONT (reset(seed=None), shortest_path.py:49-52): like a queued regeneration the slot moves to its next episode, but the
+  // run.cont (reset(seed=None), shortest_path.py:49-52): like a queued regeneration the slot moves to its next episode, but the
   // two streams are the ones its previous regeneration left in stream_state, not freshly seeded ones.
-  const bool restart = (mode == GE_RESET_ALL) || (mode == GE_RESET_INJECT && inj.seeds);
-  const bool next = (mode == GE_RESET_QUEUE || mode == GE_RESET_CONT);
+  // run.refill: P.buf is the engine's spare image; seed[] / episode[] (shared with the live slabs) name the episode the slot is
+  // still running, the image receives the one after it.
+  const bool restart = run.restart != 0;
+  const bool next = run.next != 0;
+  const bool queued = run.items == GE_ITEMS_QUEUE && !run.refill;  // a finished slot regenerated in place
   const int64_t episode = restart ? 0 : P.buf.episode[env] + (next ? 1 : 0);
-  const uint32_t seed = restart ? (mode == GE_RESET_ALL ? seeds[env] : inj.seeds[env]) : P.buf.seed[env] + (next ? (uint32_t)P.seed_stride : 0u);
+  const uint32_t seed = restart ? (run.restart == 1 ? seeds[env] : inj.seeds[env]) : P.buf.seed[env] + (next ? (uint32_t)P.seed_stride : 0u);
   const int ring = (int)(episode % GE_SEED_DEPTH);
   // where the streams are left (recomputed at each use: nothing about it stays live through the kernel)
   auto keep_at = [&](int which) -> uint32_t * { return P.buf.stream_state ? P.buf.stream_state + ((int64_t)env * 2 + which) * GE_STREAM_WORDS : nullptr; };
   // a stream's read position when this regeneration starts: a freshly seeded state is twisted before its first draw
-  auto pos0 = [&](int which) -> int { return mode == GE_RESET_CONT ? (int)keep_at(which)[GE_MT_N] : GE_MT_N; };
+  auto pos0 = [&](int which) -> int { return run.cont ? (int)keep_at(which)[GE_MT_N] : GE_MT_N; };
   const uint32_t *mt_src = P.buf.mt_state + ((int64_t)env * GE_SEED_DEPTH + ring) * 2 * GE_MT_N;
-  if (mode == GE_RESET_CONT) mt_src = keep_at(0);
+  if (run.cont) mt_src = keep_at(0);
   int src = 0, dest = -1;
   int ppd_pk[5] = {-1, -1, -1, -1, -1}, ppd_dp[5] = {-1, -1, -1, -1, -1};  // perishable_product_delivery.py:72-73
   bool gen_failed = false;
   double ppd_dt = 0.0;
   if (wv == 1) {
-    if (mode != GE_RESET_INJECT) { ge_numpy_wave<ENV>(P, c, mode == GE_RESET_CONT ? keep_at(1) : mt_src + GE_MT_N, lane, env, pos0(1), keep_at(1)); ge_sync(); }
+    if (!run.inject) { ge_numpy_wave<ENV>(P, c, run.cont ? keep_at(1) : mt_src + GE_MT_N, lane, env, pos0(1), keep_at(1)); ge_sync(); }
     ge_sync();
     return;
   }
 
   GE_STAMP(0);
-  if (mode != GE_RESET_INJECT) {
+  if (!run.inject) {
     // ---------------------------------------------------------------- topology (python stream)
     ge_mt_load(c.mt, mt_src, lane);  // pre-seeded (ge_k_seed)
     GE_STAMP(1);
@@ -1136,7 +1138,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   GE_STAMP(2);
   // ------------------------------------------------------------------ CSR in insertion order (needs the topology only: it runs
   // while the numpy wave, the longer of the two, is still drawing)
-  if (mode != GE_RESET_INJECT) {
+  if (!run.inject) {
     for (int v = lane; v < n; v += GE_WAVE) { int d = 0; for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]); c.fill[v] = d; }
     ge_wave_sync();
   }
@@ -1151,7 +1153,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     if (lane == 0) c.rowptr[n] = carry;
     ge_wave_sync();
   }
-  if (mode == GE_RESET_INJECT) {
+  if (run.inject) {
     for (int idx = lane; idx < E; idx += GE_WAVE) {
       int u = (int)inj.links[(ebase + idx) * 2], v = (int)inj.links[(ebase + idx) * 2 + 1];
       c.colw[idx] = (uint16_t)((v << 4) | (inj.wcode[ebase + idx] & 15));
@@ -1190,9 +1192,9 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   }
 
   GE_STAMP(3);
-  if (mode != GE_RESET_INJECT && t != GE_PERISHABLE_DELIVERY) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
+  if (!run.inject && t != GE_PERISHABLE_DELIVERY) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
   // ------------------------------------------------------------------ weight codes + terminals
-  if (mode != GE_RESET_INJECT) {
+  if (!run.inject) {
     for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
     ge_wave_sync();
     const bool path_like = path_like_t;
@@ -1271,7 +1273,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   GE_STAMP(6);
   // ------------------------------------------------------------------ baselines (is_eval_env)
   double heuristic = 0.0;
-  if (mode != GE_RESET_INJECT && P.is_eval) {
+  if (!run.inject && P.is_eval) {
     const double kNaN = __builtin_nan("");
     if (t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH || (t == GE_STEINER_TREE && P.n_dests == 1)) {
       ge_dijkstra_wave(c, n, src, lane);
@@ -1292,7 +1294,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
 
   // ------------------------------------------------------------------ multicast: delay bound (multicast_routing.py:101-106)
   double max_distance = 0.0;
-  if (mode != GE_RESET_INJECT && t == GE_MULTICAST_ROUTING) {
+  if (!run.inject && t == GE_MULTICAST_ROUTING) {
     ge_dijkstra_wave(c, n, 0, lane);
     double fn = -__builtin_inf(), ft = -__builtin_inf();  // farthest node, farthest destination
     for (int v = lane; v < n; v += GE_WAVE) { const double d = c.sigma[v]; if (d > fn) fn = d; }
@@ -1308,7 +1310,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   }
 
   if (t == GE_DISTRIBUTION_CENTER) heuristic = -1.0;  // distribution_center.py:91, eval or not
-  if (mode != GE_RESET_INJECT && t == GE_PERISHABLE_DELIVERY) {
+  if (!run.inject && t == GE_PERISHABLE_DELIVERY) {
     heuristic = 0.0;
     if (P.is_eval) {  // perishable_product_delivery.py:147-154: curr_node stays the head; total += a; total += b
       double d0[5];
@@ -1336,7 +1338,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
     tbits[lane] = tb;
   }
   ge_wave_sync();
-  if (mode == GE_RESET_INJECT) {
+  if (run.inject) {
     for (int idx = lane; idx < n * F; idx += GE_WAVE) G.x[nbase * F + idx] = inj.x[nbase * F + idx];
   } else {  // flag columns only; the five structural columns are written by the features kernel
     const int nf = P.nflag;
@@ -1496,18 +1498,18 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
   for (int k = lane; k < T; k += GE_WAVE) G.terminals[(int64_t)env * T + k] = (t == GE_TSP) ? 0 : ((t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? -1 : ((t == GE_DISTRIBUTION_CENTER && k >= P.n_dests) ? -1 : c.perm[k]));
   if (lane == 0) {
     const uint64_t head16 = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET || t == GE_DISTRIBUTION_CENTER) ? GE_REC_HEAD_MASK : (uint64_t)src;
-    uint64_t status = (mode == GE_RESET_QUEUE && P.autoreset == 2) ? 3ull : 0ull;  // 3: regenerated at the start of this ge_step (next-step mode)
+    uint64_t status = (queued && P.autoreset == 2) ? 3ull : 0ull;  // 3: regenerated at the start of this ge_step (next-step mode)
     if (gen_failed) status = 4ull;
     const uint64_t aux = ((t == GE_SHORTEST_PATH || t == GE_LONGEST_PATH) && W == 1) ? (uint64_t)dest : 0ull;
     // transitions since the last full reset survive a regeneration (the device policy is keyed by them)
-    const uint64_t tstep = (mode == GE_RESET_QUEUE) ? (G.slot_rec[2 * (int64_t)env + 1] >> GE_REC_TSTEP_SHIFT) : 0ull;
+    const uint64_t tstep = queued ? (G.slot_rec[2 * (int64_t)env + 1] >> GE_REC_TSTEP_SHIFT) : 0ull;
     G.slot_rec[2 * (int64_t)env] = 0ull;  // cost = +0.0
     G.slot_rec[2 * (int64_t)env + 1] = head16 | (status << GE_REC_STATUS_SHIFT) | (aux << GE_REC_AUX_SHIFT) | (tstep << GE_REC_TSTEP_SHIFT);
     G.counters[env * 2] = 0; G.counters[env * 2 + 1] = 0;
-    if (mode == GE_RESET_QUEUE) G.final_heur[env] = G.heuristic[env];  // of the episode that just ended (same-step autoreset reads it after this kernel)
+    if (queued) G.final_heur[env] = G.heuristic[env];  // of the episode that just ended (same-step autoreset reads it after this kernel)
     G.heuristic[env] = heuristic;
-    if (mode != GE_RESET_QUEUE) { G.seed[env] = seed; G.episode[env] = episode; }
-    if (t == GE_PERISHABLE_DELIVERY && mode != GE_RESET_INJECT) G.target_bits[(int64_t)env * W] = ge_f64_as_u64(ppd_dt);  // info['time_left'] of reset() (perishable_product_delivery.py:158) as float64 bits: this env has no target set
+    if (run.items != GE_ITEMS_QUEUE) { G.seed[env] = seed; G.episode[env] = episode; }  // (a queue launch: the feature kernel advances them, or -- refill -- the swap)
+    if (t == GE_PERISHABLE_DELIVERY && !run.inject) G.target_bits[(int64_t)env * W] = ge_f64_as_u64(ppd_dt);  // info['time_left'] of reset() (perishable_product_delivery.py:158) as float64 bits: this env has no target set
   }
   ge_sync();
   GE_STAMP(10);
@@ -1515,9 +1517,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, in
 
 // Queue mode: every step workgroup left (count, segment) in reset_count / reset_list; each reset workgroup
 // rebuilds the exclusive prefix of the counts in LDS and finds its slot by binary search.
-GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) {  // one wave; no barrier
-  const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  const int32_t *rc = P.buf.reset_count;
+GE_DEV int ge_queue_prefix_of(const int32_t *rc, int nblk, int *pre, int lane) {  // one wave; no barrier
   int carry = 0;
   for (int k0 = 0; k0 < nblk; k0 += GE_WAVE) {
     int k = k0 + lane; int cnt = k < nblk ? rc[k] : 0;
@@ -1528,11 +1528,13 @@ GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) {  // one
   if (lane == 0) pre[nblk] = carry;
   return carry;
 }
-GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) {
-  int lo = 0, hi = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+GE_DEV int ge_queue_prefix_wave(const GeParams &P, int *pre, int lane) { return ge_queue_prefix_of(P.buf.reset_count, (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK, pre, lane); }
+GE_DEV int ge_queue_slot_of(const int32_t *list, int nblk, const int *pre, int q) {
+  int lo = 0, hi = nblk;
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid; }
-  return P.buf.reset_list[lo * GE_STEP_BLOCK + (q - pre[lo])];
+  return list[lo * GE_STEP_BLOCK + (q - pre[lo])];
 }
+GE_DEV int ge_queue_slot(const GeParams &P, const int *pre, int q) { return ge_queue_slot_of(P.buf.reset_list, (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK, pre, q); }
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1673,24 +1675,32 @@ GE_DEV void ge_advance_episode(const GeParams &P, int env) {
   P.buf.seed[env] = P.buf.seed[env] + (uint32_t)P.seed_stride;
   P.buf.episode[env] = P.buf.episode[env] + 1;
 }
+// ... or, when the launch refilled the slot's spare image, marks the image valid (the slot keeps running its episode; the swap
+// that moves the image in advances seed[] / episode[])
+GE_DEV void ge_finish_item(const GeParams &P, const GeRun &run, int env) {
+  if (run.refill) P.spare_state[env] = 1; else ge_advance_episode(P, env);
+}
 
-// Queue mode: the first `nseed` workgroups of the launch are seeding workgroups (64 queued slots each): they refill the ring
-// entry the slot's PREVIOUS regeneration consumed with the states of the episode GE_SEED_DEPTH ahead of the one that just
-// ended, while the other workgroups regenerate the queued slots from the entries seeded long ago -- no second stream, no event.
+// Queue launches: the first `nseed` workgroups are seeding workgroups (64 queued slots each): they write the generator states
+// of a later episode of the slot (run.seed_ahead episodes past the one seed[] / episode[] name) into the ring entry that episode
+// will be read from, while the other workgroups regenerate the queued slots from the entries seeded long ago -- no second
+// stream, no event.  Without spares seed_ahead = GE_SEED_DEPTH: the entry of the episode that just ended is refilled.  With
+// spares every regeneration runs one episode earlier relative to its use, and seed_ahead = 2 ("Episode prefetch").
 // RAGGED (multi-class engine): P is the engine-wide parameter block (B = all slots; queue, seed[], episode[], mt_state are global
 // arrays in slot order) and every workgroup looks up the class of its slot: R.classes[class] is that class's uniform sub-engine.
 template <int ENV, bool RAGGED>
-GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, GeRagged R, const uint32_t *seeds, int mode, GeInject inj, int nseed) {
+GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, GeRagged R, const uint32_t *seeds, GeRun run, GeInject inj, int nseed) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  const bool queue = run.items == GE_ITEMS_QUEUE;
   int count = P.B;
-  if (mode == GE_RESET_QUEUE) {
+  if (queue) {
     if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
     ge_sync();
     count = pre[nblk];
   }
-  if (mode == GE_RESET_QUEUE && ge_bid() < nseed) {
+  if (queue && ge_bid() < nseed) {
     for (int g0 = ge_bid() * GE_WAVE; g0 < count; g0 += nseed * GE_WAVE) {
       const int tid = ge_tid_fresh();
       if (g0 != ge_bid() * GE_WAVE) { if (tid < GE_WAVE) ge_queue_prefix_wave(P, pre, tid); ge_sync(); }
@@ -1698,19 +1708,19 @@ GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, G
       uint32_t sb = 0xffffffffu, seed = 0u;
       if (q < count) {
         const int env = ge_queue_slot(P, pre, q);
-        const int64_t ep = P.buf.episode[env];  // the episode that just ended: its entry is free, episode ep + DEPTH goes there
+        const int64_t ep = P.buf.episode[env] + run.seed_ahead;  // the episode whose states are written now
         sb = (uint32_t)env * GE_SEED_DEPTH + (uint32_t)(ep % GE_SEED_DEPTH);
-        seed = P.buf.seed[env] + (uint32_t)GE_SEED_DEPTH * (uint32_t)P.seed_stride;
+        seed = P.buf.seed[env] + (uint32_t)run.seed_ahead * (uint32_t)P.seed_stride;
       }
       ge_sync();  // every lane has its item before the scratch (which holds the queue prefix) is reused
       ge_seed_group(P, ge_dyn_smem(), sb, seed, tid);
     }
     return;
   }
-  const int first = (mode == GE_RESET_QUEUE) ? nseed : 0, stride = ge_gdim() - first;
+  const int first = queue ? nseed : 0, stride = ge_gdim() - first;
   for (int q = ge_bid() - first; q < count; q += stride) {
     int env = q;
-    if (mode == GE_RESET_QUEUE) {
+    if (queue) {
       if (q != ge_bid() - first) { const int t2 = ge_tid_fresh(); if (t2 < GE_WAVE) ge_queue_prefix_wave(P, pre, t2); ge_sync(); }
       env = ge_queue_slot(P, pre, q);
       ge_sync();  // every thread has its slot before the scratch is reused
@@ -1718,9 +1728,9 @@ GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, G
     if constexpr (RAGGED) {
       const int cls = (int)ge_uniform_u32((uint32_t)R.slot_class[env]);
       const int lo = R.class_start[cls];
-      ge_reset_env<ENV>(R.classes[cls], env - lo, seeds ? seeds + lo : seeds, mode, inj);
+      ge_reset_env<ENV>(R.classes[cls], env - lo, seeds ? seeds + lo : seeds, run, inj);
     } else {
-      ge_reset_env<ENV>(P, env, seeds, mode, inj);
+      ge_reset_env<ENV>(P, env, seeds, run, inj);
     }
   }
 }

@@ -32,16 +32,25 @@ GE_DEV uint64_t ge_rec_make(int head, int status, int aux, uint64_t tstep) {
 
 // Finished slots of this workgroup go to the workgroup's own segment of reset_list, in slot order, and the segment length to
 // reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
-GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want) {
-  const uint64_t b = ge_ballot(want);
+// With spares attached (ge_attach_spares) a finished slot whose spare image is valid goes to the swap queue (swap_list / swap_count,
+// same layout) instead: `swap` says which.  wcnt: 2 ints per wave of the workgroup.
+GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want, bool swap = false) {
+  const bool wr = want && !swap, ws = want && swap;
+  const uint64_t b = ge_ballot(wr), b2 = ge_ballot(ws);
   const int lane = tid & 63, wave = tid >> 6, nw = ge_bdim() >> 6;
-  const int rank = ge_popc64(b & ((1ull << lane) - 1ull));
-  if (lane == 0) wcnt[wave] = ge_popc64(b);
+  const uint64_t below = (1ull << lane) - 1ull;
+  if (lane == 0) { wcnt[wave] = ge_popc64(b); wcnt[nw + wave] = ge_popc64(b2); }
   ge_sync();
-  int off = 0;
-  for (int w = 0; w < wave; w++) off += wcnt[w];
-  if (want) P.buf.reset_list[i0 + off + rank] = i;
-  if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[ge_bid()] = tot; }
+  int off = 0, off2 = 0;
+  for (int w = 0; w < wave; w++) { off += wcnt[w]; off2 += wcnt[nw + w]; }
+  if (wr) P.buf.reset_list[i0 + off + ge_popc64(b & below)] = i;
+  if (ws) P.swap_list[i0 + off2 + ge_popc64(b2 & below)] = i;
+  if (tid == 0) {
+    int tot = 0, tot2 = 0;
+    for (int w = 0; w < nw; w++) { tot += wcnt[w]; tot2 += wcnt[nw + w]; }
+    P.buf.reset_count[ge_bid()] = tot;
+    if (P.swap_count) P.swap_count[ge_bid()] = tot2;
+  }
 }
 
 #define GE_MAXW 8  // parenting >= 2 walks the residual graph per thread: node sets of up to 8 words (n <= 512)
@@ -124,7 +133,7 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
   const bool edge_mask = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
   bool wrote_mask = false;  // this slot's node mask changed and sits in `stage`
 
-  bool want_reset = false;
+  bool want_reset = false, want_swap = false;
 
   if (ig < PG.B) {
     const int64_t nbase = (int64_t)i * n;
@@ -477,6 +486,8 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
         if (P.autoreset != 1) G.final_heur[i] = G.heuristic[i];  // same-step autoreset: the reset kernel copies it before it overwrites `heuristic`
         if (P.autoreset) {
           want_reset = true;
+          want_swap = PG.spare_state && PG.spare_state[ig];  // the slot's next episode waits in its spare image
+          if (want_swap) PG.spare_state[ig] = 0;
           st_out = 2;
           if (P.autoreset == 1) wrote_mask = false;  // same-step: the reset kernel rewrites the whole slot right away
         } else {
@@ -496,7 +507,7 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
 
   uint8_t *flag = (uint8_t *)(stage + (size_t)ge_bdim() * WS);
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(PG, (int *)(flag + ge_bdim()), i0, ig, tid, want_reset);  // contains the barrier; global slot ids
+  ge_enqueue_reset(PG, (int *)(flag + ge_bdim()), i0, ig, tid, want_reset, want_swap);  // contains the barrier; global slot ids
   if (edge_mask || RAGGED) return;  // SteinerTree updates its [B, 2m] mask incrementally above
   // ---- bool mask slab: [B, n] bytes, this workgroup owns the contiguous range of its slots
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
@@ -546,12 +557,13 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
   uint64_t *stage = (uint64_t *)ge_dyn_smem();
   uint8_t *flag = (uint8_t *)(stage + ge_bdim());
   bool wrote_mask = false;
-  bool want_reset = false;
+  bool want_reset = false, want_swap = false;
   if (i < P.B) {
     // ---- phase A, round 1: slot state (coalesced)
     const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
     const uint64_t mb = G.mask_bits[i];
     const uint64_t vis0 = G.node_bits[i];
+    const uint8_t spare = P.spare_state ? P.spare_state[i] : (uint8_t)0;  // 1: the slot's next episode waits in its spare image
     const int head = (int)(rec.y & 63ull), st = ge_rec_status(rec.y), dest = ge_rec_aux(rec.y);
     const uint64_t ts = ge_rec_tstep(rec.y);
     const double cost0 = ge_u64_as_f64(rec.x);
@@ -606,6 +618,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     }
     const bool fin = acted && done;
     want_reset = fin && P.autoreset;
+    want_swap = want_reset && spare;
     wrote_mask = moved && !open_mask && !(want_reset && P.autoreset == 1);  // same-step: the reset kernel rewrites the slot right away
     stage[tid] = nm;
     // a slot regenerated at the start of this step (status 3, next-step autoreset) ignored its action and runs from the next step on
@@ -630,6 +643,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
       if (GE_ON(16)) G.node_bits[i] = vis;
     }
     if (wrote_mask && GE_ON(16)) G.mask_bits[i] = nm;
+    if (want_swap) P.spare_state[i] = 0;
     if (fin) {
       G.final_cost[i] = cost;
       G.final_len[i] = ge_popc64(vis0);  // every move adds one node to the visited set, which starts as {source}
@@ -637,7 +651,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     }
   }
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset);  // contains the barrier
+  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, want_swap);  // contains the barrier
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
   if (nb <= 0 || !GE_ON(2)) return;
   uint8_t *out = G.mask + (int64_t)i0 * n;

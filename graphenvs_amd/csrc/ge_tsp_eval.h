@@ -31,22 +31,22 @@
 GE_DEV int32_t ge_tsp_units(const GeParams &P, double w) { return (int32_t)llrint(w * 65536.0); }
 
 // items of the launch: every slot (full reset) or the queued ones; `pre` (LDS) holds the queue prefix in queue mode
-GE_DEV int ge_tsp_count(const GeParams &P, int *pre, int mode) {
-  if (mode != GE_RESET_QUEUE) return P.B;
+GE_DEV int ge_tsp_count(const GeParams &P, int *pre, int queue) {
+  if (!queue) return P.B;
   if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
   ge_sync();
   return pre[(P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK];
 }
 
-GE_KERNEL ge_k_tsp_closure(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes, int pre_off) {
+GE_KERNEL ge_k_tsp_closure(GeParams P, int queue, uint8_t *scratch, uint64_t slot_bytes, int pre_off) {
   uint64_t *done_all = (uint64_t *)ge_dyn_smem();  // [64 lanes][W] settled sets
   int *pre = (int *)(ge_dyn_smem() + pre_off);
-  const int count = ge_tsp_count(P, pre, mode);
+  const int count = ge_tsp_count(P, pre, queue);
   const int n = P.n, W = P.W, lane = ge_tid();
   uint64_t *done = done_all + lane * W;
   const ge_buffers &G = P.buf;
   for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    const int env = queue ? ge_queue_slot(P, pre, q) : q;
     int32_t *D = (int32_t *)(scratch + (uint64_t)env * slot_bytes);
     const int32_t *rp = G.row_ptr + (int64_t)env * (n + 1);
     const int64_t ebase = (int64_t)env * P.E;
@@ -78,12 +78,12 @@ GE_KERNEL ge_k_tsp_closure(GeParams P, int mode, uint8_t *scratch, uint64_t slot
   }
 }
 
-GE_KERNEL ge_k_tsp_tour(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
+GE_KERNEL ge_k_tsp_tour(GeParams P, int queue, uint8_t *scratch, uint64_t slot_bytes) {
   int *pre = (int *)ge_dyn_smem();
-  const int count = ge_tsp_count(P, pre, mode);
+  const int count = ge_tsp_count(P, pre, queue);
   const int n = P.n;
   for (int q = ge_bid() * GE_TSP_EVAL_THREADS + ge_tid(); q < count; q += ge_gdim() * GE_TSP_EVAL_THREADS) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    const int env = queue ? ge_queue_slot(P, pre, q) : q;
     uint8_t *blk = scratch + (uint64_t)env * slot_bytes;
     ge_ch c;
     c.err = 0;
@@ -98,13 +98,13 @@ GE_KERNEL ge_k_tsp_tour(GeParams P, int mode, uint8_t *scratch, uint64_t slot_by
 // (max_independent_set.py:63-67), networkx's clique removal reproduced exactly (ge_clique_removal.h: dict orders of the graph
 // copies, CPython's set tables).  One LANE per regenerated slot on the slot's scratch block; replaces the min-degree greedy value
 // the graph kernel left in heuristic[] (which stays if the work space were ever too small).  Evaluation-time path, like the above.
-GE_KERNEL ge_k_mis_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
+GE_KERNEL ge_k_mis_baseline(GeParams P, int queue, uint8_t *scratch, uint64_t slot_bytes) {
   int *pre = (int *)ge_dyn_smem();
-  const int count = ge_tsp_count(P, pre, mode);
+  const int count = ge_tsp_count(P, pre, queue);
   const int n = P.n;
   const ge_buffers &G = P.buf;
   for (int q = ge_bid() * GE_TSP_EVAL_THREADS + ge_tid(); q < count; q += ge_gdim() * GE_TSP_EVAL_THREADS) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    const int env = queue ? ge_queue_slot(P, pre, q) : q;
     ge_cr_work w;
     ge_cr_carve(&w, scratch + (uint64_t)env * slot_bytes, n, P.m);
     const int32_t *rp = G.row_ptr + (int64_t)env * (n + 1);
@@ -124,13 +124,13 @@ GE_HOSTDEV uint64_t ge_steiner_slot_bytes(int n, int m, int T) {
   return ((((uint64_t)(2 * m + 1) * 2) + 15) & ~15ull) + ((((uint64_t)(2 * m + 1) * 8) + 15) & ~15ull) + ge_kou_arena_bytes(n, m, T);
 }
 
-GE_KERNEL ge_k_steiner_baseline(GeParams P, int mode, uint8_t *scratch, uint64_t slot_bytes) {
+GE_KERNEL ge_k_steiner_baseline(GeParams P, int queue, uint8_t *scratch, uint64_t slot_bytes) {
   int *pre = (int *)ge_dyn_smem();
-  const int count = ge_tsp_count(P, pre, mode);
+  const int count = ge_tsp_count(P, pre, queue);
   const int n = P.n;
   const ge_buffers &G = P.buf;
   for (int q = ge_bid() * GE_TSP_EVAL_THREADS + ge_tid(); q < count; q += ge_gdim() * GE_TSP_EVAL_THREADS) {
-    const int env = (mode == GE_RESET_QUEUE) ? ge_queue_slot(P, pre, q) : q;
+    const int env = queue ? ge_queue_slot(P, pre, q) : q;
     uint8_t *blk = scratch + (uint64_t)env * slot_bytes;
     uint16_t *adj = (uint16_t *)blk;
     double *w = (double *)(blk + ((((uint64_t)(2 * P.m + 1) * 2) + 15) & ~15ull));

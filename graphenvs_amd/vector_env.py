@@ -139,7 +139,8 @@ class VectorGraphEnv(_VectorBase):
 
     def __init__(self, env_id, num_envs, n_nodes, n_edges=-1, device="cuda", autoreset=True, obs_mode="pyg",
                  env_index_base=0, seed_stride=None, strict=False, _library=None, _views=None, node_id_base=0,
-                 edge_row_stride=0, record_actions=False, copy_outputs=False, continue_streams=False, _defer_create=False, **kwargs):
+                 edge_row_stride=0, record_actions=False, copy_outputs=False, continue_streams=False, _defer_create=False, prefetch=None,
+                 **kwargs):
         self.env_id = env_id
         self.kwargs = normalize_kwargs(env_id, n_nodes, n_edges, **kwargs)
         self.num_envs = int(num_envs)
@@ -245,6 +246,16 @@ class VectorGraphEnv(_VectorBase):
         if not _defer_create:  # (a size class of a multi-class engine is created by RaggedVectorEnv, all classes at once)
             _lib.check(self._L, self._L.ge_create(C.byref(self.cfg), C.byref(self.bufs), C.byref(h)), "ge_create")
         self._h = h
+        # episode prefetch (include/graphenvs.h, ge_attach_spares): every slot's NEXT episode is generated ahead of time into a spare
+        # image, `prefetch` steps' worth of finished slots per launch, and moved in by one copy when the slot finishes.  Same outputs
+        # with and without; it pays where few slots finish per step (long episodes, large graphs), where a regeneration in place
+        # makes the whole step wait for the latency of a few slots.  None = the engine's choice for this env id and size, 0 = off.
+        self.prefetch = self.default_prefetch(env_id, self.n, self.num_envs) if prefetch is None else int(prefetch)
+        if not self.autoreset or self.continue_streams:
+            self.prefetch = 0
+        self.spare = None
+        if self.prefetch and not _defer_create:
+            self._attach_spares()
         # static parts of the PyG view
         self._batch = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(n)
         self._ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n + int(node_id_base)
@@ -262,6 +273,30 @@ class VectorGraphEnv(_VectorBase):
             self.action_space = sp.MultiDiscrete([self.m if edge_env else n] * B) if hasattr(sp, "MultiDiscrete") else None
             self.observation_space = sp.Box(low=-np.inf, high=np.inf, shape=(B, self.obs_len), dtype=np.float32)
             self.metadata = {"autoreset_mode": {0: "disabled", 1: "same_step", 2: "next_step"}[self.autoreset_mode]}
+
+    @staticmethod
+    def default_prefetch(env_id, n, num_envs):
+        """refill period chosen when the caller does not say (0 = regenerate in place): see DESIGN.md, "Episode prefetch" """
+        return 0
+
+    def _image_tensors(self, views=None):
+        """a second set of the per-slot slabs (ge_spares.image); `views`: slabs given by the caller (multi-class engine)"""
+        img = {}
+        for k in _lib.IMAGE_FIELDS:
+            live = dict.__getitem__(self.t, k)
+            img[k] = None if live is None else (views[k] if views and k in views else torch.zeros_like(live))
+        return img
+
+    def _attach_spares(self):
+        B, dev = self.num_envs, self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        img = self._image_tensors()
+        sp = dict(state=z((B,), torch.uint8), swap_list=z((B,), torch.int32), swap_count=z(((B + 255) // 256,), torch.int32),
+                  refill_list=z((B,), torch.int32), refill_count=z(((B + 255) // 256,), torch.int32))
+        self.spare = dict(image=img, **sp)
+        rec = _lib.GeSpares(_lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in img.items()}),
+                            *(sp[k].data_ptr() for k in ("state", "swap_list", "swap_count", "refill_list", "refill_count")), self.prefetch)
+        _lib.check(self._L, self._L.ge_attach_spares(self._h, C.byref(rec), None), "ge_attach_spares")
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -462,13 +497,22 @@ class VectorGraphEnv(_VectorBase):
     def state_dict(self):
         """Snapshot of every engine slab: the whole state of the batch, generator states included."""
         self._quiesce()
-        return {k: v.clone() for k, v in dict.items(self.t) if v is not None and k != "eval_scratch"}  # work space, not state
+        sd = {k: v.clone() for k, v in dict.items(self.t) if v is not None and k != "eval_scratch"}  # work space, not state
+        if self.spare is not None:  # the images themselves are not state (they are regenerated); the marker says which invariant the generator ring obeys
+            sd["_prefetch"] = torch.ones((), dtype=torch.int32)
+        return sd
 
     def load_state_dict(self, sd):
         self._quiesce()
+        # an engine with spares seeds its generator ring one episode later than one without: a snapshot of the former only restores
+        # into an engine with spares (the other direction is fine)
+        assert "_prefetch" not in sd or self.spare is not None, "snapshot of an engine with prefetch: restore into an engine with prefetch"
         for k, v in sd.items():
-            dict.__getitem__(self.t, k).copy_(v)
-        self._L.ge_mark_restored(self._h)
+            if k != "_prefetch":
+                dict.__getitem__(self.t, k).copy_(v)
+        if self.spare is not None:
+            self.spare["state"].zero_()  # every image is regenerated at the next opportunity
+        _lib.check(self._L, self._L.ge_mark_restored(self._h), "ge_mark_restored")
         self._was_reset = True
         self._streams = self.continue_streams and "stream_state" in sd
         self._quiesce()

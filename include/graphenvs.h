@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 3
+#define GE_ABI_VERSION 4
 
 /* env ids of graph_envs/__init__.py:9-56 that are on the hot path */
 enum {
@@ -199,6 +199,30 @@ int ge_destroy(ge_engine *e);
 int64_t ge_ragged_table_bytes(int32_t n_classes);
 int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, int32_t n_classes, void *class_table,
                      int32_t *slot_class, int32_t *class_start, ge_engine **out);
+
+/* Episode prefetch ("spares").  reset() of the reference (shortest_path.py:47-98 and siblings) is a pure function of its seed, and the
+ * k-th autoreset episode of a slot is seeded s0 + k * seed_stride: it can be produced before the slot needs it.  With spares attached
+ * every slot owns an IMAGE -- a second set of the per-slot slabs (observation, CSR, masks, scalar state) -- that the reset path fills
+ * for many slots per launch, every `period` calls of ge_step; a slot that finishes with a valid image gets it by one streaming copy
+ * inside the same ge_step (same-step autoreset) / the next one (next-step autoreset) instead of a regeneration whose latency the whole
+ * step would wait for; a slot that finishes again before its image was refilled is regenerated in place as without spares.  Every
+ * output of every call is the same with and without spares, whatever the period.
+ *  - image: like the ge_buffers of ge_create, but only the per-slot slabs are read: x, edge_index, edge_attr, row_ptr, colw, scode,
+ *    adj_bits, slot_rec, terminals, node_bits, target_bits, counters, heuristic, mask, mask_bits and, where the engine has them,
+ *    sw64, node_rec, rev_edge, aux_bits, node_aux, range_bits, cover_bits -- same sizes as the live ones.  (The image of a class of
+ *    a multi-class engine packs its observation slabs exactly like the live ones: same node_id_base / edge_row_stride.)
+ *  - state [B] uint8 (zeroed by the caller), swap_list / refill_list [B] int32, swap_count / refill_count [ceil(B/256)] int32.
+ * Multi-class engine: sp is an array of n_classes entries (entry c: the image of class c; state / lists / period are taken from
+ * entry 0 and cover ALL slots) and class_table_spare is a second device buffer of ge_ragged_table_bytes(n_classes) bytes; else
+ * sp points at one entry and class_table_spare is NULL.  Not available together with ge_buffers.stream_state. */
+typedef struct {
+  ge_buffers image;
+  uint8_t *state;
+  int32_t *swap_list, *swap_count;
+  int32_t *refill_list, *refill_count;
+  int32_t period;
+} ge_spares;
+int ge_attach_spares(ge_engine *e, const ge_spares *sp, void *class_table_spare);
 
 /* env.reset(seed=s) for every slot (shortest_path.py:47-98 and the five siblings):
  * seeds [B] uint32 on device = first-episode seed per slot (read on `stream` only); sets episode = 0.

@@ -71,6 +71,63 @@ def test_emulated_batch_autoreset_matches_oracle(emu, n, m):  # walks round the 
     assert sum(eps) > B
 
 
+def _prefetch_rollout(emu, env_id, kw, B, K, period, autoreset=True, stride=1000):
+    """an engine with spares (episode prefetch) against the oracle: rewards, done, info, masks and the whole observation after
+    every step; returns (episodes, how many of them were served by a spare image)"""
+    import oracle
+    env = ge.VectorGraphEnv(env_id, B, device="cpu", _library=emu, seed_stride=stride, env_index_base=3, prefetch=period,
+                            autoreset=autoreset, obs_mode="flat", **kw)
+    env.reset(seed=5)
+    refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+    eps, pend, swaps = [0] * B, [False] * B, 0
+    for i, r in enumerate(refs):
+        r.reset(seed=5 + 3 + i)
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=9).clone().numpy()
+        valid = env.spare["state"].clone().numpy()
+        _, rew, term, _, info = env.step(a)
+        for i, r in enumerate(refs):
+            if pend[i]:  # next-step autoreset: this step regenerated the slot and ignored its action
+                eps[i] += 1
+                r.reset(seed=(5 + 3 + i + eps[i] * stride) % 2**32)
+                pend[i] = False
+                assert float(rew[i]) == 0 and not bool(term[i])
+            else:
+                _, rr, dd, _, inf = r.step(int(a[i]))
+                assert float(rew[i]) == rr and bool(term[i]) == dd, (k, i)
+                if dd:
+                    assert float(info["solution_cost"][i]) == inf["solution_cost"]
+                    assert float(info["heuristic_solution"][i]) == inf["heuristic_solution"]
+                    swaps += int(valid[i])
+                    if autoreset == "next_step":
+                        pend[i] = True
+                    else:
+                        eps[i] += 1
+                        r.reset(seed=(5 + 3 + i + eps[i] * stride) % 2**32)
+            assert np.array_equal(info["mask"][i].numpy(), r.mask()), (k, i)
+        flat = env.flat_obs().numpy()
+        for i, r in enumerate(refs):
+            assert np.array_equal(flat[i], r.obs()), (k, i)
+    env.close()
+    return sum(eps), swaps
+
+
+@pytest.mark.parametrize("env_id,kw,B,K,period,autoreset", [
+    ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, is_eval_env=True), 6, 40, 1, True),
+    ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, is_eval_env=True), 6, 40, 7, True),
+    ("ShortestPath-v0", dict(n_nodes=4, n_edges=5, is_eval_env=True), 6, 40, 4, True),   # episodes of one or two steps: most finish again before the refill
+    ("ShortestPath-v0", dict(n_nodes=10, n_edges=20, is_eval_env=True), 6, 40, 3, "next_step"),
+    ("SteinerTree-v0", dict(n_nodes=12, n_edges=30, n_dests=3, is_eval_env=True), 5, 40, 5, True),
+    ("DistributionCenter-v0", dict(n_nodes=12, n_edges=25), 5, 30, 2, True),
+    ("ShortestPath-v0", dict(n_nodes=70, n_edges=160), 3, 36, 4, True),                    # generic feature kernel, feat_parts workgroups
+])
+def test_emulated_prefetch_matches_oracle(emu, env_id, kw, B, K, period, autoreset):
+    episodes, swaps = _prefetch_rollout(emu, env_id, kw, B, K, period, autoreset)
+    assert episodes >= B and swaps > 0
+    if kw["n_nodes"] == 4:
+        assert swaps < episodes  # both ways of getting the next episode ran: the image, and the regeneration in place
+
+
 @pytest.mark.parametrize("env_id,kw", [("ShortestPath-v0", dict(n_nodes=12, n_edges=30)),
                                        ("LongestPath-v0", dict(n_nodes=12, n_edges=30, parenting=1)),
                                        ("SteinerTree-v0", dict(n_nodes=12, n_edges=30, n_dests=3))])

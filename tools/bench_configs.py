@@ -42,8 +42,9 @@ for name in (sys.argv[1:] or ["c3", "c4"]):
     if name == "c5":
         bench_c5()
         continue
+    name, _, pf = name.partition("@")  # name@period: with episode prefetch (spares), refill every `period` steps
     env_id, kw, B, K = CONFIGS[name]
-    env = ge.make_vec(env_id, B, **kw)
+    env = ge.make_vec(env_id, B, prefetch=(int(pf) if pf else None), **kw)
     # the first launch of a kernel instantiation pays its code-object load (round 1's 106 ms "full reset" of the first config in the
     # list was that): one untimed reset first, the timed one after it
     env.reset(seed=1); torch.cuda.synchronize()
@@ -51,6 +52,6 @@ for name in (sys.argv[1:] or ["c3", "c4"]):
     env.random_rollout(10, policy_seed=1); torch.cuda.synchronize()
     ep0 = int(env.t["episode"].sum())
     t0 = time.perf_counter(); env.random_rollout(K, policy_seed=1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(config=name, env=env_id, kwargs=kw, envs=B, steps=K, env_steps_per_s=B * K / dt, ms_per_vector_step=dt * 1e3 / K,
+    print(json.dumps(dict(config=name, prefetch=env.prefetch, env=env_id, kwargs=kw, envs=B, steps=K, env_steps_per_s=B * K / dt, ms_per_vector_step=dt * 1e3 / K,
                           episodes=int(env.t["episode"].sum()) - ep0, full_reset_ms=t_reset * 1e3)), flush=True)
     env.close(); del env; torch.cuda.empty_cache()
