@@ -244,6 +244,13 @@ static int finish_create(ge_engine *e, ge_engine **out) {
     else GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_reset<ENV, false>), reset_lds));
     if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
+  // ---- quad-per-slot step kernel of the edge-action envs: its LDS stage (mask rows + node sets of 256 slots) passes 64 KB
+  if (!rg && (P.env_type == GE_STEINER_TREE || P.env_type == GE_MULTICAST_ROUTING) && ge_edge_fits(P.AW, P.W) && ge_edge_lds_bytes(P.AW, P.W) > 64 * 1024) {
+    const int bytes = (int)ge_edge_lds_bytes(P.AW, P.W);
+    if (P.env_type == GE_STEINER_TREE) { hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_STEINER_TREE, true>), bytes); if (hr == hipSuccess) hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_STEINER_TREE, false>), bytes); }
+    else { hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_MULTICAST_ROUTING, true>), bytes); if (hr == hipSuccess) hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_MULTICAST_ROUTING, false>), bytes); }
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the edge step kernel"); }
+  }
   // ---- feature kernels
   e->feat_fast = any64 ? 1 : 0;  // (spatial TSP: float64 weights do not fit the fast path's LDS)
   e->feat64_pre_off = ge_align16(f64_body + 8);
@@ -428,10 +435,10 @@ static int launch_seed(ge_engine *e, const uint32_t *seeds, int jlo, void *strea
 }
 
 // V: the engine (e->P) or its spare-image view (e->PS); VR: the matching class table
-static int launch_combine(ge_engine *e, const GeParams &V, const GeRagged &VR, GeRun run, void *stream) {
+static int launch_combine(ge_engine *e, const GeParams &V, const GeRagged &VR, GeRun run, bool small, void *stream) {
   const bool rg = e->n_classes > 0;
   size_t lds = (size_t)((V.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4;
-  int64_t items = (int64_t)(run.items == GE_ITEMS_ALL ? V.B : 4096) * V.n;
+  int64_t items = (int64_t)(run.items == GE_ITEMS_ALL ? V.B : (small ? 64 : 4096)) * V.n;
   int grid = (int)((items + 255) / 256); if (grid > 8192) grid = 8192;
   if (rg) GE_LAUNCH(ge_k_feat_combine<true>, grid, 256, lds, stream, V, VR, run);
   else GE_LAUNCH(ge_k_feat_combine<false>, grid, 256, lds, stream, V, VR, run);
@@ -443,7 +450,7 @@ static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, 
   int rc = GE_OK;
   const bool rg = e->n_classes > 0, queue = run.items == GE_ITEMS_QUEUE;
   int fgrid = queue ? e->feat_grid : (V.B < e->feat_grid * 4 ? V.B : e->feat_grid * 4);
-  if (small && fgrid > 256) fgrid = 256;
+  if (small && fgrid > 64) fgrid = 64;
   const int gen_threads = GE_WAVE * (rg ? e->classes[0].ldsf.waves : V.ldsf.waves);
   if (e->feat_fast) {
     if (rg) GE_LAUNCH(ge_k_features64<true>, fgrid, GE_F64_THREADS, e->feat_lds, stream, V, VR, run, e->feat64_pre_off);
@@ -453,11 +460,11 @@ static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, 
     // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64, feat_parts workgroups each
     if (rg) {
       int64_t want = (int64_t)e->gen_grid * ge_feat_workgroups(V.feat_parts) * (queue ? 1 : 4);
-      if (small && want > 1024) want = 1024;
+      if (small && want > 288) want = 288;
       if (want > 65535 * 16) want = 65535 * 16;
       GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off);
       rc = check_launch("feature kernel (list)");
-      return (rc == GE_OK && V.feat_parts > 1) ? launch_combine(e, V, VR, as_list(run), stream) : rc;
+      return (rc == GE_OK && V.feat_parts > 1) ? launch_combine(e, V, VR, as_list(run), small, stream) : rc;
     }
     int g2 = e->gen_grid < 64 ? e->gen_grid : 64;
     GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off);
@@ -466,14 +473,14 @@ static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, 
   {
     int64_t want = (int64_t)fgrid * ge_feat_workgroups(V.feat_parts);
     if (queue && !run.refill && want > 4608) want = 4608;  // the list is short, workgroups stride over it
-    if (small && want > 1152) want = 1152;
+    if (small && want > 288) want = 288;
     if (want > 65535 * 16) want = 65535 * 16;
     if (rg) GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off);
     else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off);
   }
   rc = check_launch("feature kernel");
   if (rc != GE_OK || V.feat_parts == 1) return rc;
-  return launch_combine(e, V, VR, run, stream);
+  return launch_combine(e, V, VR, run, small, stream);
 }
 
 // is_eval_env baselines that are sequential programs (ge_tsp_eval.h: TSP Christofides, MaxIndependentSet clique removal) for the
@@ -518,7 +525,7 @@ static int launch_reset(ge_engine *e, const GeParams &V, const GeRagged &VR, con
     if (rc != GE_OK) return rc;
   }
   int rgrid = e->reset_grid, nseed = e->nseed;
-  if (small && rgrid > 512) { rgrid = 512; nseed = 8; }
+  if (small && rgrid > 128) { rgrid = 128; nseed = 2; }
   if (!queue) nseed = 0;
   const int grid = queue ? rgrid + nseed : (V.B < e->reset_grid * 4 ? V.B : e->reset_grid * 4);
   if (e->n_classes > 0) GE_FOR_RAGGED_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed));
@@ -607,6 +614,8 @@ static bool prunes(const ge_engine *e) { return (e->P.env_type == GE_LONGEST_PAT
   do {                                                                                                                                  \
     if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, true, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
     else if (path64(e)) GE_LAUNCH(ge_k_step_path64<SAMPLE>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
+    else if (edge_quad(e) && e->P.env_type == GE_STEINER_TREE) GE_LAUNCH((ge_k_step_edge<GE_STEINER_TREE, SAMPLE>), grid, GE_EDGE_THREADS, ge_edge_lds_bytes(e->P.AW, e->P.W), stream, e->P, actions_arg, seed_arg); \
+    else if (edge_quad(e)) GE_LAUNCH((ge_k_step_edge<GE_MULTICAST_ROUTING, SAMPLE>), grid, GE_EDGE_THREADS, ge_edge_lds_bytes(e->P.AW, e->P.W), stream, e->P, actions_arg, seed_arg); \
     else if (prunes(e) && e->P.env_type == GE_TSP) GE_LAUNCH((ge_k_step<GE_TSP, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
     else if (prunes(e)) GE_LAUNCH((ge_k_step<GE_LONGEST_PATH, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
     else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, false, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
@@ -614,6 +623,11 @@ static bool prunes(const ge_engine *e) { return (e->P.env_type == GE_LONGEST_PAT
 
 static bool path64(const ge_engine *e);
 static size_t step_lds(const ge_engine *e);
+// SteinerTree / MulticastRouting whose mask rows fit the LDS stage of the quad-per-slot kernel (ge_step.h, ge_k_step_edge)
+static bool edge_quad(const ge_engine *e) {
+  static const bool off = getenv("GE_NO_EDGE_QUAD") != nullptr;  // diagnostic: the thread-per-slot kernel (before / after measurements)
+  return !off && e->n_classes == 0 && (e->P.env_type == GE_STEINER_TREE || e->P.env_type == GE_MULTICAST_ROUTING) && ge_edge_fits(e->P.AW, e->P.W);
+}
 
 static bool path64(const ge_engine *e) {
   return e->n_classes == 0 && (e->P.env_type == GE_SHORTEST_PATH || e->P.env_type == GE_LONGEST_PATH) && e->P.W == 1 && e->P.parenting < 2;
@@ -665,7 +679,7 @@ extern "C" int ge_reset_pending(ge_engine *e, void *stream) {
     GeInject none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (e->spares) {  // finished slots with a valid image: one streaming copy each
       const int nblk = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-      int64_t grid = 2048 * (int64_t)(e->swap_parts > 4 ? 4 : e->swap_parts);
+      int64_t grid = 1024;  // workgroups stride over (slot, part) items; most steps have a few hundred
       if (grid > (int64_t)e->P.B * e->swap_parts) grid = (int64_t)e->P.B * e->swap_parts;
       if (e->n_classes > 0) GE_LAUNCH(ge_k_swap<true>, (int)grid, 256, (nblk + 2) * 4, stream, e->P, e->R, e->RS, e->PS.buf, e->swap_parts);
       else GE_LAUNCH(ge_k_swap<false>, (int)grid, 256, (nblk + 2) * 4, stream, e->P, e->R, e->RS, e->PS.buf, e->swap_parts);

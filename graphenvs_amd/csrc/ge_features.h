@@ -15,6 +15,7 @@ struct GeFctx {
   double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's slice)
   double *bcw0;                                 // slice of wave 0 (the per-wave partial sums are combined in wave order)
   double *bc, *prx, *prn, *sinv, *diff, *clos;  // shared
+  uint16_t *ord, *lvl;                          // per wave: BFS order of the current source; lvl[d] = where level d starts in it
 };
 
 GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
@@ -30,6 +31,7 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   double *wsc = f + 6 * P.n;  // [waves][4][n]
   c.bcw0 = wsc + 3 * P.n;
   c.sigma = wsc + (wv * 4) * P.n; c.delta = c.sigma + P.n; c.coeff = c.sigma + 2 * P.n; c.bcw = c.sigma + 3 * P.n;
+  c.ord = (uint16_t *)(s + L.ord + wv * L.ord_stride); c.lvl = c.ord + ((2 * P.n + 15) & ~15) / 2;
   return c;
 }
 
@@ -65,34 +67,69 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
   const bool trivial = (P.complete && P.ng == n) || node_part;
   if (trivial && !node_part) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
+  // One BFS per source, frontier by frontier: the nodes of a source's search are kept in discovery order (ord) with the start of
+  // every level (lvl), so that each pass touches the nodes of ONE level and their rows -- O(n + E) per source where scanning every
+  // node at every level was O(levels x (n + E)).  Forward: the lanes take the nodes of level d and push their path counts to the
+  // neighbours that are unvisited or already at level d + 1 (ds_add_f64 on integer-valued counts: exact in any order); the next
+  // level is then collected in ascending node order.  Backward: pull, as before -- a node of level lev - 1 adds sigma(v) * coeff(w)
+  // over its row in row order, so every float64 sum has the order it always had.
+  const uint64_t below = (1ull << lane) - 1ull;
   for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
     for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
+    if (lane == 0) { c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; }
     ge_wave_sync();
-    int d = 0, reach = 1; int64_t tot = 0;
-    for (;;) {  // forward: discover level d+1, sigma by pull from level d (a push by the frontier with ds_add_f64 was measured
-      // slower: C4 feature kernel 501 -> 560 us)
-      // a node moves from -1 to d+1, never to d, so lanes still testing dist[u] == d are unaffected
-      uint64_t any = 0; int found = 0;
-      for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
-        int v = k0 + lane; bool hit = false;
-        if (v < n && c.dist[v] < 0) {
-          double sg = 0.0;
-          for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int u = c.colw[k] >> 4; if (c.dist[u] == d) { sg += c.sigma[u]; hit = true; } }
-          if (hit) { c.sigma[v] = sg; c.dist[v] = d + 1; }
+    int d = 0, reach = 1, lo = 0, hi = 1; int64_t tot = 0;
+    for (;;) {
+      for (int k = lo + lane; k < hi; k += GE_WAVE) {
+        const int u = c.ord[k]; const double su = c.sigma[u];
+        const int r1 = c.rowptr[u + 1];
+        for (int e = c.rowptr[u]; e < r1; e += 4) {  // four edges per trip: the LDS round trips (column, level) of the four overlap
+          int v[4], dv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
+#pragma unroll
+          for (int j = 0; j < 4; j++) dv[j] = (v[j] >= 0) ? c.dist[v[j]] : 0x7fffffff;
+#pragma unroll
+          for (int j = 0; j < 4; j++) if (v[j] >= 0) {
+            if (dv[j] < 0) { c.dist[v[j]] = d + 1; dv[j] = d + 1; }   // (several lanes may discover v: they all write the same level)
+            if (dv[j] == d + 1) ge_lds_add_f64(&c.sigma[v[j]], su);
+          }
         }
-        uint64_t b = ge_ballot(hit);
-        any |= b; found += ge_popc64(b);
       }
       ge_wave_sync();
-      if (!any) break;
-      d++; reach += found; tot += (int64_t)d * found;
-    }
-    for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
-      for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev) { c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bcw[v] += c.delta[v]; }
+      int found = 0;
+      for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+        const int v = k0 + lane;
+        const bool hit = v < n && c.dist[v] == d + 1;
+        const uint64_t b = ge_ballot(hit);
+        if (hit) c.ord[hi + found + ge_popc64(b & below)] = (uint16_t)v;
+        found += ge_popc64(b);
+      }
+      if (!found) break;
+      d++; lo = hi; hi += found; reach += found; tot += (int64_t)d * found;
+      if (lane == 0) c.lvl[d + 1] = (uint16_t)hi;
       ge_wave_sync();
-      for (int v = lane; v < n; v += GE_WAVE) if (c.dist[v] == lev - 1) {
-        double acc = 0.0, sv = c.sigma[v];
-        for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) { int w = c.colw[k] >> 4; if (c.dist[w] == lev) acc += sv * c.coeff[w]; }
+    }
+    ge_wave_sync();
+    for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
+      const int l0 = c.lvl[lev], l1 = c.lvl[lev + 1], p0 = c.lvl[lev - 1];
+      for (int k = l0 + lane; k < l1; k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bcw[v] += c.delta[v]; }
+      ge_wave_sync();
+      for (int k = p0 + lane; k < l0; k += GE_WAVE) {
+        const int v = c.ord[k];
+        double acc = 0.0; const double sv = c.sigma[v];
+        const int r1 = c.rowptr[v + 1];
+        for (int e = c.rowptr[v]; e < r1; e += 4) {  // four edges per trip; the sum keeps its row order
+          int w[4]; bool on[4]; double cf[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) w[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
+#pragma unroll
+          for (int j = 0; j < 4; j++) on[j] = w[j] >= 0 && c.dist[w[j]] == lev;
+#pragma unroll
+          for (int j = 0; j < 4; j++) cf[j] = on[j] ? c.coeff[w[j]] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) if (on[j]) acc += sv * cf[j];
+        }
         c.delta[v] = acc;
       }
       ge_wave_sync();

@@ -48,6 +48,7 @@ struct GeLds {
 struct GeLdsF {
   int abits, rowptr, colw, scw, dist, f64a, pre, total;
   int waves;  // waves per workgroup of the generic feature kernel (1..8, as many as LDS allows)
+  int ord, ord_stride;  // per wave: u16[n] BFS order of the current source, then u16[n + 2] where each level starts in it
 };
 
 struct GeParams {
@@ -164,5 +165,8 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   L.waves = waves;
   L.dist = take(waves * P.n * 4);
   L.f64a = take((6 + 4 * waves) * P.n * 8);
+  // (allocated behind everything the wave count was sized for: the count -- hence the float64 summation order -- is that of round 2)
+  L.ord_stride = ge_align16(2 * P.n) + ge_align16(2 * (P.n + 2));
+  L.ord = take(waves * L.ord_stride);
   L.total = o;
 }

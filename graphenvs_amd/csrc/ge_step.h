@@ -533,6 +533,227 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
   }
 }
 
+// Edge-action envs (SteinerTree, MulticastRouting: one action per directed edge, [B, 2m] masks), a QUAD of lanes per slot.
+// A workgroup is 1 024 threads for the same 256 slots a thread-per-slot workgroup would own (the reset queue keeps its layout) --
+// four times the waves to hide the five dependent memory round trips of a transition (slot state -> chosen edge -> row extents ->
+// row -> reverse edges), and every per-slot access a quad makes is one 32-byte sector instead of four:
+//  * the workgroup's 256 mask rows (contiguous in mask_bits) and node sets are staged in LDS with coalesced loads;
+//  * SAMPLE: the device policy's "r-th set bit of the row" is a popcount per lane over the words q, q + 4, ... and a prefix over
+//    the quad (DPP), not a scan of 32 words per thread;
+//  * the row of the node that joins the tree is walked four edges at a time; mask words are updated with LDS atomics and only the
+//    words that changed are written back, together with the bool bytes of the edges that changed (an edge v -> u opens iff u is
+//    outside the tree; the reverse edge u -> v was open iff u is inside: only those are touched).
+// Replaces step() / _get_mask() of steiner_tree.py:116-157 and multicast_routing.py:155-266 for graphs whose rows fit the LDS stage
+// (ge_edge_fits); larger ones keep the thread-per-slot kernel above.
+#define GE_EDGE_LPS 4
+#define GE_EDGE_THREADS (GE_STEP_BLOCK * GE_EDGE_LPS)
+GE_HOSTDEV int ge_edge_row_stride(int AW) { return AW + 4; }  // + 32 bytes: the quads of a wave start their rows in different banks
+GE_HOSTDEV size_t ge_edge_lds_bytes(int AW, int W) { return (size_t)GE_STEP_BLOCK * (size_t)(ge_edge_row_stride(AW) + W) * 8 + 2 * (GE_EDGE_THREADS / 64) * 4 + 64; }
+GE_HOSTDEV bool ge_edge_fits(int AW, int W) { return AW <= 32 && ge_edge_lds_bytes(AW, W) <= 100 * 1024; }
+
+GE_DEV uint32_t ge_quad_or32(uint32_t v) { v |= ge_quad_xor1(v); v |= ge_quad_xor2(v); return v; }
+GE_DEV uint64_t ge_quad_or64(uint64_t v) { return (uint64_t)ge_quad_or32((uint32_t)v) | ((uint64_t)ge_quad_or32((uint32_t)(v >> 32)) << 32); }
+
+// the words of a slot's mask row that changed (bit w of `dirty`), dealt over the lanes of the quad
+GE_DEV void ge_edge_writeback(uint64_t *dst, const uint64_t *row, uint32_t dirty, int q) {
+  int idx = 0;
+  for (uint32_t m = dirty; m; m &= m - 1, idx++) if ((idx & (GE_EDGE_LPS - 1)) == q) { const int w = (int)__builtin_ctz(m); dst[w] = row[w]; }
+}
+
+template <int ENV, bool SAMPLE>
+GE_KERNEL_LB(GE_EDGE_THREADS, 1) ge_k_step_edge(GeParams P, const int64_t *actions, uint64_t policy_seed) {
+  static_assert(ENV == GE_STEINER_TREE || ENV == GE_MULTICAST_ROUTING, "edge-action envs");
+  const ge_buffers &G = P.buf;
+  const int tid = ge_tid(), q = tid & (GE_EDGE_LPS - 1);
+  const int i0 = ge_bid() * GE_STEP_BLOCK, sl = tid >> 2, i = i0 + sl;  // slot of this quad
+  const int n = P.n, W = P.W, F = P.F, A = P.A, AW = P.AW, RS = ge_edge_row_stride(AW);
+  uint64_t *rows = (uint64_t *)ge_dyn_smem();           // [256][RS] mask rows
+  uint64_t *nbs = rows + (size_t)GE_STEP_BLOCK * RS;    // [256][W] node sets (in tree / has the message)
+  int *wcnt = (int *)(nbs + (size_t)GE_STEP_BLOCK * W);
+  int nb = P.B - i0; if (nb > GE_STEP_BLOCK) nb = GE_STEP_BLOCK;
+  // ---- stage: the workgroup's mask rows and node sets are contiguous in HBM
+  for (int idx = tid; idx < nb * AW; idx += GE_EDGE_THREADS) { const int e = idx / AW, w = idx - e * AW; rows[e * RS + w] = G.mask_bits[(int64_t)i0 * AW + idx]; }
+  for (int idx = tid; idx < nb * W; idx += GE_EDGE_THREADS) nbs[idx] = G.node_bits[(int64_t)i0 * W + idx];
+  ge_sync();
+  uint64_t *row = rows + sl * RS, *nbits = nbs + sl * W;
+  bool want_reset = false, want_swap = false;
+  if (i < P.B) {
+    const int64_t nbase = (int64_t)i * n, ebase = (int64_t)i * P.E;
+    const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
+    const int st = ge_rec_status(rec.y);
+    uint64_t ts = ge_rec_tstep(rec.y);
+    // ---- action
+    int64_t a64;
+    if (SAMPLE) {
+      // words q, q + 4, ...: chunk j of the row is the words 4 j .. 4 j + 3, one per lane, so word order is (chunk, lane) order
+      uint64_t wd[8]; uint32_t cnt = 0, ctot[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        wd[j] = (4 * j + q < AW) ? row[4 * j + q] : 0ull;
+        const uint64_t g = ge_quad_gather16((uint32_t)ge_popc64(wd[j]));
+        ctot[j] = (uint32_t)((g & 0xffffu) + ((g >> 16) & 0xffffu) + ((g >> 32) & 0xffffu) + (g >> 48));
+        cnt += ctot[j];
+      }
+      a64 = -1;
+      if (cnt && st != 1 && st != 4) {
+        const uint64_t z = ge_mix64(policy_seed + (uint64_t)(P.env_index_base + i) * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
+        uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
+        int jsel = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) if (jsel == j && r >= ctot[j]) { r -= ctot[j]; jsel = j + 1; }
+        uint64_t wsel = wd[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) if (jsel == j) wsel = wd[j];
+        const uint32_t mine = (uint32_t)ge_popc64(wsel);
+        const uint64_t g = ge_quad_gather16(mine);
+        const uint32_t c0 = (uint32_t)(g & 0xffffu), c1 = (uint32_t)((g >> 16) & 0xffffu), c2 = (uint32_t)((g >> 32) & 0xffffu);
+        const int qsel = r < c0 ? 0 : (r < c0 + c1 ? 1 : (r < c0 + c1 + c2 ? 2 : 3));
+        const uint32_t before = (q > 0 ? c0 : 0u) + (q > 1 ? c1 : 0u) + (q > 2 ? c2 : 0u);
+        const uint32_t rr = (q == qsel) ? r - before : 0u;
+        const uint32_t bit = (q == qsel) ? (uint32_t)ge_nth_set_bit(wsel, rr) : 0u;
+        const uint64_t gb = ge_quad_gather16(bit);
+        a64 = (int64_t)(4 * jsel + qsel) * 64 + (int64_t)((gb >> (16 * qsel)) & 0xffffu);
+      }
+      if (q == 0 && G.actions_out) G.actions_out[i] = a64;
+    } else {
+      a64 = actions[i];
+    }
+    double cost = ge_u64_as_f64(rec.x);
+    double reward = 0.0; int done = 0, solved = -1, invalid = 0; bool acted = false, cost_hidden = false;
+    if (st == 0 && a64 != -1) {
+      const bool in_range = a64 >= 0 && a64 < (int64_t)A;
+      const int a = in_range ? (int)a64 : 0;
+      const bool mbit = in_range && ((row[a >> 6] >> (a & 63)) & 1ull);
+      if (!mbit) invalid = 1;
+      else {
+        acted = true;
+        const uint16_t ea = G.colw[ebase + a];
+        const int v = ea >> 4;
+        const float delay = (float)ge_wlut(ea & 15);
+        float r = -delay;
+        float c32 = (float)cost; c32 -= r; cost = (double)c32;  // numpy float32 accumulator
+        uint8_t *mby = G.mask + (int64_t)i * A;
+        const int32_t *rp = G.row_ptr + (int64_t)i * (n + 1);
+        if constexpr (ENV == GE_STEINER_TREE) {  // steiner_tree.py:123-157
+          const int r0 = rp[v], r1 = rp[v + 1];
+          reward = (double)r;
+          if (q == 0) { G.x[(nbase + v) * F + 0] = 1.f; nbits[v >> 6] |= 1ull << (v & 63); }
+          ge_quad_sync();
+          uint32_t dirty = 0;  // words of the row that changed
+          for (int k = r0 + q; k < r1; k += GE_EDGE_LPS) {
+            const int u = G.colw[ebase + k] >> 4;
+            if (!((nbits[u >> 6] >> (u & 63)) & 1ull)) { atomicOr((unsigned long long *)&row[k >> 6], 1ull << (k & 63)); mby[k] = 1; dirty |= 1u << (k >> 6); }  // v -> u opens
+            else {  // u -> v closes (it was open: u in the tree, v outside until now)
+              const int rk = G.rev_edge[ebase + k];
+              atomicAnd((unsigned long long *)&row[rk >> 6], ~(1ull << (rk & 63))); mby[rk] = 0; dirty |= 1u << (rk >> 6);
+            }
+          }
+          ge_quad_sync();
+          ge_edge_writeback(G.mask_bits + (int64_t)i * AW, row, ge_quad_or32(dirty), q);
+          uint64_t missing = 0;
+          for (int w = q; w < W; w += GE_EDGE_LPS) { missing |= G.target_bits[(int64_t)i * W + w] & ~nbits[w]; G.node_bits[(int64_t)i * W + w] = nbits[w]; }
+          if (!ge_quad_or64(missing)) { done = 1; solved = 1; }
+        } else {  // multicast_routing.py:191-266
+          cost_hidden = true;
+          const int u = (int)(G.edge_index[ebase + a] - P.node_id_base - nbase);
+          const double fail = -2.0 * n * P.n_dests;
+          const bool has_u = (nbits[u >> 6] >> (u & 63)) & 1ull, has_v = (nbits[v >> 6] >> (v & 63)) & 1ull;
+          if (!has_u || has_v) { done = 1; solved = 0; reward = fail; }  // :211-217 (parenting 1 only): nothing changes
+          else {
+            const float dv = G.x[(nbase + u) * F + 3] + delay;  // float32 + float32
+            ge_quad_sync();  // (every lane has read the sets before lane 0 changes them)
+            if (q == 0) {
+              nbits[v >> 6] |= 1ull << (v & 63);
+              G.x[(nbase + v) * F + 0] = 1.f; G.x[(nbase + v) * F + 3] = dv;
+              G.edge_attr[(ebase + a) * 2 + 1] = 1.f;
+            }
+            ge_quad_sync();
+            const int r0 = rp[v], r1 = rp[v + 1];
+            // the mask after the move (also returned by the failure exits below)
+            if (P.parenting == 1) {  // not taken
+              if (q == 0) { row[a >> 6] &= ~(1ull << (a & 63)); mby[a] = 0; G.mask_bits[(int64_t)i * AW + (a >> 6)] = row[a >> 6]; }
+            } else if (P.parenting == 2) {  // tree -> outside edges
+              uint32_t dirty = 0;
+              for (int k = r0 + q; k < r1; k += GE_EDGE_LPS) {
+                const int w = G.colw[ebase + k] >> 4;
+                if (!((nbits[w >> 6] >> (w & 63)) & 1ull)) { atomicOr((unsigned long long *)&row[k >> 6], 1ull << (k & 63)); mby[k] = 1; dirty |= 1u << (k >> 6); }
+                else {
+                  const int rk = G.rev_edge[ebase + k];
+                  atomicAnd((unsigned long long *)&row[rk >> 6], ~(1ull << (rk & 63))); mby[rk] = 0; dirty |= 1u << (rk >> 6);
+                }
+              }
+              ge_quad_sync();
+              ge_edge_writeback(G.mask_bits + (int64_t)i * AW, row, ge_quad_or32(dirty), q);
+            } else {  // per outside node the tree edge of smallest float32 distance, first index on ties (np.argmin)
+              int32_t *best = G.node_aux + nbase;
+              uint32_t dirty = 1u << (a >> 6);
+              if (q == 0) { row[a >> 6] &= ~(1ull << (a & 63)); mby[a] = 0; best[v] = -1; }  // a == best[v]
+              ge_quad_sync();
+              for (int k = r0 + q; k < r1; k += GE_EDGE_LPS) {  // the neighbours of a row are distinct nodes: the lanes update different entries of best[]
+                const uint16_t ek = G.colw[ebase + k];
+                const int w = ek >> 4;
+                if ((nbits[w >> 6] >> (w & 63)) & 1ull) continue;
+                const float dn = dv + (float)ge_wlut(ek & 15);
+                const int cur = best[w];
+                bool take = cur < 0;
+                if (!take) {
+                  const int uc = (int)(G.edge_index[ebase + cur] - P.node_id_base - nbase);
+                  const float dc = G.x[(nbase + uc) * F + 3] + (float)ge_wlut(G.colw[ebase + cur] & 15);
+                  take = dn < dc || (dn == dc && k < cur);
+                  if (take) { atomicAnd((unsigned long long *)&row[cur >> 6], ~(1ull << (cur & 63))); mby[cur] = 0; dirty |= 1u << (cur >> 6); }
+                }
+                if (take) { best[w] = k; atomicOr((unsigned long long *)&row[k >> 6], 1ull << (k & 63)); mby[k] = 1; dirty |= 1u << (k >> 6); }
+              }
+              ge_quad_sync();
+              ge_edge_writeback(G.mask_bits + (int64_t)i * AW, row, ge_quad_or32(dirty), q);
+            }
+            ge_quad_sync();
+            const bool is_t = (G.target_bits[(int64_t)i * W + (v >> 6)] >> (v & 63)) & 1ull;
+            bool late = false;
+            if (is_t) {
+              if (dv > G.x[(nbase + v) * F + 2] + 1e-4f) late = true;  // :230, float32
+              else r += 1.f;
+            }
+            uint64_t missing = 0, any = 0;
+            for (int w = q; w < W; w += GE_EDGE_LPS) { missing |= G.target_bits[(int64_t)i * W + w] & ~nbits[w]; G.node_bits[(int64_t)i * W + w] = nbits[w]; }
+            for (int w = q; w < AW; w += GE_EDGE_LPS) any |= row[w];
+            missing = ge_quad_or64(missing); any = ge_quad_or64(any);
+            reward = (double)r;
+            if (late) { done = 1; solved = 0; reward = fail; }
+            else if (!missing) { done = 1; solved = 1; cost_hidden = false; }
+            else if (!any) { done = 1; solved = 0; reward = fail; }
+          }
+        }
+      }
+    }
+    if (q == 0) {
+      G.reward[i] = reward;
+      G.terminated[i] = (uint8_t)done;
+      G.invalid[i] = (uint8_t)invalid;
+      G.solved[i] = (int8_t)solved;
+      int st_out = (st == 3) ? 0 : st;  // a slot regenerated at the start of this step (next-step autoreset) runs from the next step on
+      if (acted) {
+        const int len = G.counters[i * 2 + 1] + 1;
+        G.counters[i * 2 + 1] = len;
+        ts = (ts + 1) & 0xffffffffull;
+        if (done) {
+          G.final_cost[i] = cost_hidden ? -1.0 : cost;
+          G.final_len[i] = len;
+          if (P.autoreset != 1) G.final_heur[i] = G.heuristic[i];
+          if (P.autoreset) {
+            want_reset = true;
+            want_swap = P.spare_state && P.spare_state[i];
+            if (want_swap) P.spare_state[i] = 0;
+            st_out = 2;
+          } else st_out = 1;
+        }
+      }
+      if (acted || st == 3) ((ulonglong2 *)G.slot_rec)[i] = make_ulonglong2(ge_f64_as_u64(cost), ge_rec_make(ge_rec_head(rec.y), st_out, ge_rec_aux(rec.y), ts));
+    }
+  }
+  ge_enqueue_reset(P, wcnt, i0, i, tid, want_reset, want_swap);  // contains the barrier; only lane 0 of a quad ever wants
+}
+
 // Headline fast path: ShortestPath / LongestPath(parenting 0,1) with n <= 64.  One u64 per node set.  The kernel is
 // three phases per slot: (A) every load -- the coalesced slot state (one 16-byte record {cost, packed head / status /
 // destination / step count}, the visited set, the mask), then ONE 16-byte gather for the record of the chosen node;

@@ -24,7 +24,8 @@ class RaggedVectorEnv:
     """One env id, several size classes: ``sizes = [(num_envs, n_nodes, n_edges), ...]``.  Slots are numbered class after class;
     slot g runs seed (seed + g) like a uniform engine.  ``classes[c]`` are views of class c (``.mask`` [B_c, A_c], ``.t[...]``)."""
 
-    def __init__(self, env_id, sizes, device="cuda", env_index_base=0, seed_stride=None, autoreset=True, _library=None, **kwargs):
+    def __init__(self, env_id, sizes, device="cuda", env_index_base=0, seed_stride=None, autoreset=True, _library=None, prefetch=None,
+                 **kwargs):
         self.env_id, self.device = env_id, torch.device(device)
         self.sizes = [(int(b), int(n), int(m)) for b, n, m in sizes]
         self.num_envs = B = sum(b for b, _, _ in self.sizes)
@@ -44,7 +45,7 @@ class RaggedVectorEnv:
         self.g = {k: z((B,) + shape, dt) for k, (shape, dt) in _GLOBAL.items()}
         self.g["reset_list"], self.g["reset_count"] = z((B,), torch.int32), z(((B + 255) // 256,), torch.int32)
         self.g["work_list"], self.g["work_count"] = z((B,), torch.int32), z((4,), torch.int32)
-        self.classes, self.slot_ptr = [], [0]
+        self.classes, self.slot_ptr, self._offsets = [], [0], []
         noff = eoff = slot = moff = 0
         ptr = [0]
         for b, n, m in self.sizes:
@@ -54,8 +55,9 @@ class RaggedVectorEnv:
             views.update({k: self.g[k][slot:slot + b] for k in _GLOBAL})
             views.update({k: self.g[k] for k in ("reset_list", "reset_count", "work_list", "work_count")})
             env = VectorGraphEnv(env_id, b, n, m, env_index_base=self.env_index_base + slot, seed_stride=stride, autoreset=autoreset,
-                                 _views=views, node_id_base=noff, edge_row_stride=Ne, _defer_create=True, **extra, **kwargs)
+                                 _views=views, node_id_base=noff, edge_row_stride=Ne, _defer_create=True, prefetch=0, **extra, **kwargs)
             self.classes.append(env)
+            self._offsets.append((noff, eoff, slot, moff, b, n, E, A))
             ptr += [noff + (i + 1) * n for i in range(b)]
             noff += b * n; eoff += b * E; slot += b; moff += b * A
             self.slot_ptr.append(slot)
@@ -68,12 +70,41 @@ class RaggedVectorEnv:
         _lib.check(self._L, self._L.ge_create_ragged(cfgs, bufs, nc, self._table.data_ptr(), self._slot_class.data_ptr(),
                                                      self._class_start.data_ptr(), C.byref(h)), "ge_create_ragged")
         self._h = h
+        # episode prefetch (include/graphenvs.h, ge_attach_spares): a ragged batch is where it pays most -- every step a few slots of
+        # many different sizes finish, and regenerated in place they cost the step the latency of the largest of them
+        self.prefetch = (16 if autoreset else 0) if prefetch is None else int(prefetch)
+        self.spare = None
+        if self.prefetch and autoreset:
+            self._attach_spares()
         self.ptr = torch.tensor(ptr, dtype=torch.int64, device=dev)
         self.batch = torch.repeat_interleave(torch.arange(B, device=dev), self.ptr[1:] - self.ptr[:-1])
         self._truncated = torch.zeros(B, dtype=torch.bool, device=dev)
         self._actions = z((B,), torch.int64)
         self._flat = None
         self._was_reset = False
+
+    def _attach_spares(self):
+        """a spare image of every class, packed like the live slabs (one x / edge_index / edge_attr / mask for all classes)"""
+        B, dev, nc = self.num_envs, self.device, len(self.classes)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        shared = dict(x=torch.zeros_like(self.x), edge_index=torch.zeros_like(self.edge_index), edge_attr=torch.zeros_like(self.edge_attr),
+                      mask=torch.zeros_like(self.mask_flat))
+        shared.update({k: torch.zeros_like(self.g[k]) for k in _GLOBAL if k in _lib.IMAGE_FIELDS})
+        sp = dict(state=z((B,), torch.uint8), swap_list=z((B,), torch.int32), swap_count=z(((B + 255) // 256,), torch.int32),
+                  refill_list=z((B,), torch.int32), refill_count=z(((B + 255) // 256,), torch.int32))
+        images, recs = [], []
+        for env, (noff, eoff, slot, moff, b, n, E, A) in zip(self.classes, self._offsets):
+            views = dict(x=shared["x"][noff:noff + b * n], edge_index=shared["edge_index"][0, eoff:], edge_attr=shared["edge_attr"][eoff:eoff + b * E],
+                         mask=shared["mask"][moff:moff + b * A].view(b, A))
+            views.update({k: shared[k][slot:slot + b] for k in _GLOBAL if k in _lib.IMAGE_FIELDS})
+            img = env._image_tensors(views)
+            images.append(img)
+            recs.append(_lib.GeSpares(_lib.GeBuffers(**{k: (v.data_ptr() if v is not None else None) for k, v in img.items()}),
+                                      *(sp[k].data_ptr() for k in ("state", "swap_list", "swap_count", "refill_list", "refill_count")), self.prefetch))
+        self._table_spare = torch.zeros_like(self._table)
+        self.spare = dict(images=images, shared=shared, **sp)
+        arr = (_lib.GeSpares * nc)(*recs)
+        _lib.check(self._L, self._L.ge_attach_spares(self._h, arr, self._table_spare.data_ptr()), "ge_attach_spares")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else C.c_void_p(0)

@@ -54,6 +54,7 @@ def check_ragged_mixed(ge, oracle, device, library=None, steps=25, specs=None):
             a = acts[mi].cpu().numpy(); rw = rew[mi].cpu().numpy(); tm = term[mi].cpu().numpy()
             flat = info[mi]["mask_flat"].cpu().numpy()
             off = 0
+            xs = None
             for j, (r, n, m, slot) in enumerate(rs):
                 want_a = oracle.policy_pick(r.mask(), 5, slot, tcount[mi][j])
                 assert int(a[j]) == want_a, (eid, j, k)
@@ -66,6 +67,16 @@ def check_ragged_mixed(ge, oracle, device, library=None, steps=25, specs=None):
                     r.reset(seed=(11 + slot + member.num_envs * _episode(member, j)) % 2**32)
                 assert np.array_equal(flat[off:off + r.A], r.mask()), (eid, j, k)
                 off += r.A
+                if dd or k == steps - 1:  # the regenerated observation (all five structural columns) of every autoreset, and everything at the end
+                    if xs is None:
+                        g = obs[mi]
+                        xs, ei, ea = g.x.cpu().numpy(), g.edge_index.cpu().numpy(), g.edge_attr.cpu().numpy()
+                        ebounds = np.searchsorted(ei[0], member.ptr.cpu().numpy())  # edge_index[0] is non-decreasing: slot after slot
+                    lo, hi = int(member.ptr[slot]), int(member.ptr[slot + 1])
+                    assert np.array_equal(xs[lo:hi], r.nodes()), (eid, j, k)
+                    e0, e1 = int(ebounds[slot]), int(ebounds[slot + 1])
+                    assert np.array_equal(ei[:, e0:e1].T - lo, r.edge_links()), (eid, j, k)
+                    assert np.array_equal(ea[e0:e1], r.edges()), (eid, j, k)
     assert episodes > 0
     mixed.close()
 

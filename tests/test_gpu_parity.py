@@ -558,3 +558,55 @@ def test_config5_ragged_batch_one_engine_per_env_id():
     specs = config5_specs()
     assert all(len({n for _, n, _ in sizes}) >= 64 and max(n for _, n, _ in sizes) == 512 for _, sizes, _ in specs)
     check_ragged_mixed(_ge(), oracle, "cuda", steps=70, specs=specs)
+
+
+# what an engine with episode prefetch must reproduce of the same engine without: every live slab except the generator ring (seeded
+# one episode later by design), the queues and the work space
+_PREFETCH_SKIP = ("mt_state", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch", "eval_scratch")
+PREFETCH_CASES = [
+    ("ShortestPath-v0", dict(n_nodes=64, n_edges=192, is_eval_env=True), 4096, 3, True),      # a tenth of the finished slots finish again before the refill
+    ("ShortestPath-v0", dict(n_nodes=64, n_edges=192), 4096, 1, "next_step"),
+    ("LongestPath-v0", dict(n_nodes=24, n_edges=50, parenting=2), 300, 5, True),
+    ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), 512, 16, True),             # BASELINE config 4's geometry
+    ("SteinerTree-v0", dict(n_nodes=40, n_edges=100, n_dests=5, is_eval_env=True), 200, 7, True),
+    ("TSP-v0", dict(n_nodes=20, n_edges=60, parenting=1), 300, 4, True),
+    ("TSP-v0", dict(n_nodes=70, n_edges=300, parenting=1, spatial=True), 64, 9, True),
+    ("DensestSubgraph-v0", dict(n_nodes=64, n_edges=192, parenting=1), 1000, 2, True),
+    ("MaxIndependentSet-v0", dict(n_nodes=130, n_edges=500, weighted=False, is_eval_env=True), 40, 6, True),
+    ("MulticastRouting-v0", dict(n_nodes=64, n_edges=192, n_dests=5), 1000, 5, True),
+    ("MulticastRouting-v0", dict(n_nodes=40, n_edges=100, n_dests=4, parenting=2), 300, 5, "next_step"),
+    ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), 1000, 2, True),
+    ("DistributionCenter-v0", dict(n_nodes=100, n_edges=260, weighted=False), 64, 3, True),
+    ("PerishableProductDelivery-v0", dict(n_nodes=20, n_edges=50, parenting=1), 300, 11, True),
+]
+
+
+@pytest.mark.parametrize("env_id,kw,B,period,mode", PREFETCH_CASES)
+def test_prefetch_reproduces_the_engine_without_it(env_id, kw, B, period, mode):
+    """ge_attach_spares changes when a regeneration is paid for, never what it produces: after every stretch of steps the two
+    engines hold the same slabs (observation, CSR, masks, scalar state, outputs of the last step, seed / episode of every slot)."""
+    ge = _ge()
+    a = ge.make_vec(env_id, B, prefetch=0, autoreset=mode, **kw)
+    b = ge.make_vec(env_id, B, prefetch=period, autoreset=mode, **kw)
+    assert a.spare is None and b.spare is not None
+    a.reset(seed=3); b.reset(seed=3)
+    served = 0
+    for stretch in (1, 2, 5, 13, 40) + ((120, 160) if kw["n_nodes"] >= 100 else ()):  # (episodes of config 4 last ~200 steps)
+        for _ in range(stretch):
+            valid = b.spare["state"].clone()
+            a.random_rollout(1, policy_seed=4); b.random_rollout(1, policy_seed=4)
+            served += int((valid.bool() & (b.t["terminated"] != 0)).sum())
+        for key, va in dict.items(a.t):
+            if va is None or key in _PREFETCH_SKIP:
+                continue
+            vb = dict.__getitem__(b.t, key)
+            if key == "range_bits" and a.t["aux_bits"] is not None:
+                # DistributionCenter, n <= 64: coverage rows are computed when first needed and aux_bits says which exist; the
+                # others hold whatever an earlier episode left, which differs between a regeneration in place and a copied image
+                n = kw["n_nodes"]
+                have = ((a.t["aux_bits"].view(-1, 1) >> torch.arange(n, device=va.device).view(1, -1)) & 1).bool().view(-1, 1)
+                va, vb = torch.where(have, va, torch.zeros_like(va)), torch.where(have, vb, torch.zeros_like(vb))
+            assert torch.equal(va, vb), (stretch, key)
+    assert int(a.t["episode"].sum()) > 0 and served > 0
+    a.check_device_errors(); b.check_device_errors()
+    a.close(); b.close()
