@@ -16,6 +16,18 @@
 #include "ge_tsp_eval.h"
 #include "ge_spare.h"
 
+// Multi-class engine: size classes are grouped into LDS buckets (by n_nodes: <= 128, <= 256, <= 512, larger), and the graph kernel
+// and the generic feature kernel are launched once per bucket with the dynamic LDS -- hence the residency -- of the bucket's largest
+// class (round 2 ran every class at the occupancy of n = 512: one workgroup per CU)
+#define GE_MAX_BUCKETS 4
+struct GeBucket {
+  bool used;
+  int reset_lds, reset_grid;                     // graph kernel
+  int gen_lds, gen_pre_off, gen_waves, gen_grid;  // generic feature kernel (classes with n > 64)
+  bool gen_used;
+};
+static int bucket_of(int n) { return n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)); }
+
 struct ge_engine {
   GeParams P;
   ge_config cfg;
@@ -31,6 +43,7 @@ struct ge_engine {
   GeRagged R;
   std::vector<GeParams> classes;  // host copy (ge_vectorize launches per class)
   int feat64_pre_off, gen_pre_off;
+  GeBucket bk[GE_MAX_BUCKETS];
   bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
   bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
   bool streams;   // stream_state holds the streams a regeneration left behind (ge_reset; a restored snapshot)
@@ -321,10 +334,40 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
     C.buf = bufs[c];
     start[c + 1] = start[c] + cfgs[c].num_envs;
     for (int i = start[c]; i < start[c + 1]; i++) cls_of[(size_t)i] = c;
-    if (C.n > 64) { GeParams T = C; ge_make_ldsf(T, (int)total, 0, 160 * 1024 - 2048); if (T.ldsf.waves < wmin) wmin = T.ldsf.waves; }
     if (C.n > e->classes[widest].n) widest = c;
   }
-  for (GeParams &C : e->classes) ge_make_ldsf(C, (int)total, wmin);  // one launch geometry of the generic feature kernel for every class
+  (void)wmin;
+  // one launch geometry of the generic feature kernel per LDS bucket: the wave count every class of the bucket can hold -- two
+  // workgroups per CU where that leaves at least four waves, else one
+  memset(e->bk, 0, sizeof(e->bk));
+  const int nblk_all = (int)((total + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK);
+  for (int b = 0; b < GE_MAX_BUCKETS; b++) {
+    int waves = 8; bool any = false, anygen = false;
+    for (int pass = 0; pass < 2; pass++) {  // pass 0: half a CU's LDS; pass 1 (fewer than four waves fit): all of it
+      waves = 8;
+      for (const GeParams &C : e->classes) if (bucket_of(C.n) == b && C.n > 64) {
+        GeParams T = C; ge_make_ldsf(T, (int)total, 0, pass == 0 ? 160 * 1024 / 2 : 160 * 1024 - 2048);
+        if (T.ldsf.waves < waves) waves = T.ldsf.waves;
+      }
+      if (waves >= 4) break;
+    }
+    GeBucket &K = e->bk[b];
+    for (GeParams &C : e->classes) if (bucket_of(C.n) == b) {
+      any = true;
+      C.bucket = b;
+      ge_make_ldsf(C, (int)total, waves);
+      if (C.lds.total > K.reset_lds) K.reset_lds = C.lds.total;
+      if (C.n > 64) { anygen = true; if (C.ldsf.total > K.gen_lds) K.gen_lds = C.ldsf.total; }
+    }
+    K.used = any; K.gen_used = anygen; K.gen_waves = waves;
+    if (!any) continue;
+    if (K.reset_lds < GE_SEED_LDS_BYTES) K.reset_lds = GE_SEED_LDS_BYTES;
+    { int per = kMaxLds / K.reset_lds; if (per > 16) per = 16; if (per < 1) per = 1; K.reset_grid = 256 * per; if (K.reset_grid > total) K.reset_grid = (int)total; }
+    if (anygen) {
+      K.gen_pre_off = ge_align16(K.gen_lds); K.gen_lds = K.gen_pre_off + (nblk_all + 2) * 4;
+      int per = kMaxLds / K.gen_lds; if (per > 16) per = 16; if (per < 1) per = 1; K.gen_grid = 256 * per; if (K.gen_grid > total) K.gen_grid = (int)total;
+    }
+  }
   // engine-wide block: the widest class's geometry (LDS stage of the step kernel), all slots, the global arrays of class 0
   e->P = e->classes[widest];
   e->P.B = (int32_t)total;
@@ -459,15 +502,19 @@ static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, 
     if (rc != GE_OK) return rc;
     // the fast path's fallback list (normally empty); multi-class engine: every slot of a class with n > 64, feat_parts workgroups each
     if (rg) {
-      int64_t want = (int64_t)e->gen_grid * ge_feat_workgroups(V.feat_parts) * (queue ? 1 : 4);
-      if (small && want > 288) want = 288;
-      if (want > 65535 * 16) want = 65535 * 16;
-      GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off);
-      rc = check_launch("feature kernel (list)");
+      for (int b = 0; b < GE_MAX_BUCKETS && rc == GE_OK; b++) {  // one launch per LDS bucket that has classes with n > 64
+        const GeBucket &K = e->bk[b];
+        if (!K.gen_used) continue;
+        int64_t want = (int64_t)K.gen_grid * ge_feat_workgroups(V.feat_parts) * (queue ? 1 : 4);
+        if (small && want > 288) want = 288;
+        if (want > 65535 * 16) want = 65535 * 16;
+        GE_LAUNCH(ge_k_features<true>, (int)want, GE_WAVE * K.gen_waves, K.gen_lds, stream, V, VR, as_list(run), K.gen_pre_off, b);
+        rc = check_launch("feature kernel (list)");
+      }
       return (rc == GE_OK && V.feat_parts > 1) ? launch_combine(e, V, VR, as_list(run), small, stream) : rc;
     }
     int g2 = e->gen_grid < 64 ? e->gen_grid : 64;
-    GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off);
+    GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off, -1);
     return check_launch("feature kernel (fallback list)");
   }
   {
@@ -475,8 +522,15 @@ static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, 
     if (queue && !run.refill && want > 4608) want = 4608;  // the list is short, workgroups stride over it
     if (small && want > 288) want = 288;
     if (want > 65535 * 16) want = 65535 * 16;
-    if (rg) GE_LAUNCH(ge_k_features<true>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off);
-    else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off);
+    if (rg) {  // (no class with n <= 64: every slot takes the generic kernel) one launch per LDS bucket
+      for (int b = 0; b < GE_MAX_BUCKETS && rc == GE_OK; b++) {
+        const GeBucket &K = e->bk[b];
+        if (!K.gen_used) continue;
+        GE_LAUNCH(ge_k_features<true>, (int)want, GE_WAVE * K.gen_waves, K.gen_lds, stream, V, VR, run, K.gen_pre_off, b);
+        rc = check_launch("feature kernel");
+      }
+    }
+    else GE_LAUNCH(ge_k_features<false>, (int)want, gen_threads, e->gen_lds, stream, V, VR, run, e->gen_pre_off, -1);
   }
   rc = check_launch("feature kernel");
   if (rc != GE_OK || V.feat_parts == 1) return rc;
@@ -528,9 +582,23 @@ static int launch_reset(ge_engine *e, const GeParams &V, const GeRagged &VR, con
   if (small && rgrid > 128) { rgrid = 128; nseed = 2; }
   if (!queue) nseed = 0;
   const int grid = queue ? rgrid + nseed : (V.B < e->reset_grid * 4 ? V.B : e->reset_grid * 4);
-  if (e->n_classes > 0) GE_FOR_RAGGED_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed));
-  else GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed));
-  rc = check_launch("reset kernel");
+  if (e->n_classes > 0) {
+    bool first = true;
+    for (int b = 0; b < GE_MAX_BUCKETS && rc == GE_OK; b++) {  // one launch per LDS bucket; the seeding workgroups ride in the first
+      const GeBucket &K = e->bk[b];
+      if (!K.used) continue;
+      int bg = K.reset_grid; if (small && bg > 128) bg = 128;
+      const int ns = first ? nseed : 0;
+      const int g = queue ? bg + ns : (V.B < K.reset_grid * 4 ? V.B : K.reset_grid * 4);
+      int lds = K.reset_lds;
+      GeParams V2 = V;
+      if (V.lds.pre != 0) { V2.lds.pre = ge_align16(K.reset_lds); lds = V2.lds.pre + ((V.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 2) * 4; }  // queue prefix behind the bucket's scratch
+      GE_FOR_RAGGED_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, true>), g, GE_RESET_THREADS, lds, stream, V2, VR, seeds, run, inj, ns, b));
+      rc = check_launch("reset kernel");
+      first = false;
+    }
+  } else GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed, -1));
+  if (rc == GE_OK) rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;
   if (!run.inject && e->n_classes == 0 && eval_slot_bytes(V)) rc = launch_seq_baseline(e, V, queue ? 1 : 0, stream);
   if (rc != GE_OK) return rc;

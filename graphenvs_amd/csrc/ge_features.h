@@ -25,7 +25,7 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   c.abits = (uint64_t *)(s + L.abits); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
   c.scw = (uint16_t *)(s + L.scw);
   const int wv = tid >> 6;
-  c.dist = (int *)(s + L.dist) + wv * P.n;
+  c.dist = (int *)(s + L.dist + wv * ((P.n * 4 + 15) & ~15));  // (16-byte aligned: the Brandes pass keeps its 64-bit node sets here)
   double *f = (double *)(s + L.f64a);
   c.bc = f; c.prx = f + P.n; c.prn = f + 2 * P.n; c.sinv = f + 3 * P.n; c.diff = f + 4 * P.n; c.clos = f + 5 * P.n;
   double *wsc = f + 6 * P.n;  // [waves][4][n]
@@ -40,6 +40,10 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
 // betweenness partial sums are combined in wave order, then clustering and pagerank.
 // nparts > 1: the slot's BFS sources are dealt over nparts workgroups (part 0 .. nparts-1), and ONE MORE workgroup
 // (part == nparts) does the node-level work -- clustering, pagerank, degrees -- beside them instead of behind one of them.
+#ifndef GE_FABL
+#define GE_FABL 0  // diagnostic ablation bits of the generic feature kernel (tools/variant_reset.py; the results are wrong by construction): 1 forward
+                   // push, 2 backward coefficient pass, 4 backward pull, 8 pagerank iterations; 0 when shipped
+#endif
 GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat_parts + 1 : 1; }
 GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid_fresh(), nthreads = ge_bdim();
@@ -67,73 +71,87 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
   const bool trivial = (P.complete && P.ng == n) || node_part;
   if (trivial && !node_part) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
-  // One BFS per source, frontier by frontier: the nodes of a source's search are kept in discovery order (ord) with the start of
-  // every level (lvl), so that each pass touches the nodes of ONE level and their rows -- O(n + E) per source where scanning every
-  // node at every level was O(levels x (n + E)).  Forward: the lanes take the nodes of level d and push their path counts to the
-  // neighbours that are unvisited or already at level d + 1 (ds_add_f64 on integer-valued counts: exact in any order); the next
-  // level is then collected in ascending node order.  Backward: pull, as before -- a node of level lev - 1 adds sigma(v) * coeff(w)
-  // over its row in row order, so every float64 sum has the order it always had.
+  // One BFS per source, level by level, the nodes kept in discovery order (ord) with the start of every level (lvl): each pass
+  // touches the nodes of ONE level and their rows -- O(n + E) per source.  No atomics and no per-node level array:
+  //  * the next level is found with the adjacency BIT rows: the lanes OR the rows of the current level's nodes (groups of Wp
+  //    lanes, one word each, combined with shuffles), minus the visited set;
+  //  * path counts by pull: a node of the new level adds front[u] over its row, where front[] (kept in the coefficient array,
+  //    which the forward pass does not need) holds sigma(u) for the nodes of the current level and 0 for every other node -- the
+  //    counts are integers, exact in any order;
+  //  * dependencies by pull, as always: a node of level lev - 1 adds sigma(v) * coeff(w) over its row IN ROW ORDER; coeff[] is 0
+  //    outside level lev, so the test "is w one level deeper" is gone -- a term sigma(v) * 0.0 = +0.0 leaves the sum as it is, and
+  //    every float64 sum keeps the order (and the value) it always had.
   const uint64_t below = (1ull << lane) - 1ull;
+  uint64_t *vis = (uint64_t *)c.dist, *nxt = vis + W;  // visited set / level being discovered (this wave's words)
+  int Wp = 1; while (Wp < W) Wp <<= 1;                  // lanes per group: lane = group * Wp + word
+  const int NG = GE_WAVE / Wp, gw = lane & (Wp - 1), gg = lane / Wp;
   for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
-    for (int v = lane; v < n; v += GE_WAVE) { c.dist[v] = (v == s) ? 0 : -1; c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; }
+    for (int v = lane; v < n; v += GE_WAVE) { c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; c.coeff[v] = (v == s) ? 1.0 : 0.0; }
+    if (lane < W) vis[lane] = ((s >> 6) == lane) ? (1ull << (s & 63)) : 0ull;
     if (lane == 0) { c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; }
     ge_wave_sync();
     int d = 0, reach = 1, lo = 0, hi = 1; int64_t tot = 0;
     for (;;) {
-      for (int k = lo + lane; k < hi; k += GE_WAVE) {
-        const int u = c.ord[k]; const double su = c.sigma[u];
-        const int r1 = c.rowptr[u + 1];
-        for (int e = c.rowptr[u]; e < r1; e += 4) {  // four edges per trip: the LDS round trips (column, level) of the four overlap
-          int v[4], dv[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
-#pragma unroll
-          for (int j = 0; j < 4; j++) dv[j] = (v[j] >= 0) ? c.dist[v[j]] : 0x7fffffff;
-#pragma unroll
-          for (int j = 0; j < 4; j++) if (v[j] >= 0) {
-            if (dv[j] < 0) { c.dist[v[j]] = d + 1; dv[j] = d + 1; }   // (several lanes may discover v: they all write the same level)
-            if (dv[j] == d + 1) ge_lds_add_f64(&c.sigma[v[j]], su);
-          }
-        }
-      }
+      uint64_t un = 0;
+      for (int k = lo + gg; k < hi; k += NG) { const int u = c.ord[k]; if (gw < W) un |= c.abits[u * W + gw]; }
+      for (int off = Wp; off < GE_WAVE; off <<= 1) un |= ge_shfl_u64(un, lane ^ off);
+      if (lane < W) { const uint64_t nw = un & ~vis[lane]; vis[lane] |= nw; nxt[lane] = nw; }
       ge_wave_sync();
       int found = 0;
-      for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
-        const int v = k0 + lane;
-        const bool hit = v < n && c.dist[v] == d + 1;
-        const uint64_t b = ge_ballot(hit);
-        if (hit) c.ord[hi + found + ge_popc64(b & below)] = (uint16_t)v;
+      for (int w = 0; w < W; w++) {
+        const uint64_t b = nxt[w];
+        if ((b >> lane) & 1ull) c.ord[hi + found + ge_popc64(b & below)] = (uint16_t)(w * GE_WAVE + lane);
         found += ge_popc64(b);
       }
       if (!found) break;
+      ge_wave_sync();
+      for (int k = hi + lane; k < hi + found && !(GE_FABL & 1); k += GE_WAVE) {
+        const int v = c.ord[k];
+        double acc = 0.0;
+        const int r1 = c.rowptr[v + 1];
+        for (int e = c.rowptr[v]; e < r1; e += 4) {  // four edges per trip: the LDS round trips of the four overlap
+          int u[4]; double f[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) u[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
+#pragma unroll
+          for (int j = 0; j < 4; j++) f[j] = (u[j] >= 0) ? c.coeff[u[j]] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc += f[j];
+        }
+        c.sigma[v] = acc;
+      }
+      ge_wave_sync();
+      for (int k = lo + lane; k < hi; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;                                     // the front moves on
+      for (int k = hi + lane; k < hi + found; k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = c.sigma[v]; }
       d++; lo = hi; hi += found; reach += found; tot += (int64_t)d * found;
       if (lane == 0) c.lvl[d + 1] = (uint16_t)hi;
       ge_wave_sync();
     }
+    for (int k = lo + lane; k < hi; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;  // coeff[] is all zero again
     ge_wave_sync();
     for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
       const int l0 = c.lvl[lev], l1 = c.lvl[lev + 1], p0 = c.lvl[lev - 1];
-      for (int k = l0 + lane; k < l1; k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bcw[v] += c.delta[v]; }
+      for (int k = l0 + lane; k < l1 && !(GE_FABL & 2); k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bcw[v] += c.delta[v]; }
       ge_wave_sync();
-      for (int k = p0 + lane; k < l0; k += GE_WAVE) {
+      for (int k = p0 + lane; k < l0 && !(GE_FABL & 4); k += GE_WAVE) {
         const int v = c.ord[k];
         double acc = 0.0; const double sv = c.sigma[v];
         const int r1 = c.rowptr[v + 1];
         for (int e = c.rowptr[v]; e < r1; e += 4) {  // four edges per trip; the sum keeps its row order
-          int w[4]; bool on[4]; double cf[4];
+          int w[4]; double cf[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) w[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
 #pragma unroll
-          for (int j = 0; j < 4; j++) on[j] = w[j] >= 0 && c.dist[w[j]] == lev;
+          for (int j = 0; j < 4; j++) cf[j] = (w[j] >= 0) ? c.coeff[w[j]] : 0.0;
 #pragma unroll
-          for (int j = 0; j < 4; j++) cf[j] = on[j] ? c.coeff[w[j]] : 0.0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) if (on[j]) acc += sv * cf[j];
+          for (int j = 0; j < 4; j++) acc += sv * cf[j];  // (+0.0 for a neighbour that is not one level deeper)
         }
         c.delta[v] = acc;
       }
       ge_wave_sync();
+      for (int k = l0 + lane; k < l1; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;
     }
+    ge_wave_sync();
     if (lane == 0) {  // closeness_centrality, wf_improved
       double cc = 0.0;
       if (tot > 0 && n > 1) { cc = ((double)reach - 1.0) / (double)tot; double sc = ((double)reach - 1.0) / (double)(n - 1); cc *= sc; }
@@ -183,7 +201,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   ge_sync();
   const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
   bool conv = false;
-  for (int it = 0; it < 100 && !conv; it++) {
+  for (int it = 0; it < ((GE_FABL & 8) ? 1 : 100) && !conv; it++) {
     double dsum = 0.0;
     if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
     for (int i = tid; i < n; i += nthreads) {
@@ -501,7 +519,7 @@ GE_DEV int ge_slot_class(const GeRagged &R, int env) { return (int)ge_uniform_u3
 // fast path).  pre_off: byte offset of the queue prefix inside the dynamic LDS (behind the largest class's scratch in a multi-class
 // engine).
 template <bool RAGGED>
-GE_KERNEL ge_k_features(GeParams P, GeRagged R, GeRun run, int pre_off) {
+GE_KERNEL ge_k_features(GeParams P, GeRagged R, GeRun run, int pre_off, int bucket) {
   int *pre = (int *)(ge_dyn_smem() + pre_off);
   const bool queue = run.items == GE_ITEMS_QUEUE, list = run.items == GE_ITEMS_LIST;
   int count = list ? P.buf.work_count[0] : P.B;
@@ -517,12 +535,14 @@ GE_KERNEL ge_k_features(GeParams P, GeRagged R, GeRun run, int pre_off) {
   for (int q = ge_bid(); q < count * nparts; q += ge_gdim()) {
     const int item = q / nparts, part = q % nparts;
     const int env = queue ? ge_queue_slot(P, pre, item) : (list ? P.buf.work_list[item] : item);
-    if (queue && part == 0 && ge_tid() == 0) ge_finish_item(P, run, env);  // seed[] / episode[] now name the new episode (refill: the image is valid)
     if constexpr (RAGGED) {
       const int cls = ge_slot_class(R, env);
       const GeParams &C = R.classes[cls];
+      if (bucket >= 0 && C.bucket != bucket) continue;  // one launch per LDS bucket of size classes (see ge_k_reset)
+      if (queue && part == 0 && ge_tid() == 0) ge_finish_item(P, run, env);
       if (part < ge_feat_workgroups(C.feat_parts)) ge_features_generic_env(C, env - R.class_start[cls], part, C.feat_parts);  // uniform per workgroup
     } else {
+      if (queue && part == 0 && ge_tid() == 0) ge_finish_item(P, run, env);  // seed[] / episode[] now name the new episode (refill: the image is valid)
       ge_features_generic_env(P, env, part, fparts);
     }
   }

@@ -71,6 +71,7 @@ struct GeParams {
   // instead of the regeneration queue, and a copy kernel moves the image in
   uint8_t *spare_state;
   int32_t *swap_list, *swap_count;
+  int32_t bucket;  // multi-class engine: the LDS bucket of this size class (ge_api.hip, GeBucket); 0 in a uniform engine
 };
 
 // What a launch of the reset path does.  Decoded ONCE, on the host, from a validated request (ge_api.hip: run_*), so that the
@@ -163,7 +164,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   if (P.complete && P.ng == P.n && P.n > 64) { waves = (P.n + 63) / 64; if (waves > 8) waves = 8; }  // one thread per pagerank row: more waves would only hold LDS
   if (force_waves > 0) waves = force_waves;
   L.waves = waves;
-  L.dist = take(waves * P.n * 4);
+  L.dist = take(waves * ge_align16(P.n * 4));
   L.f64a = take((6 + 4 * waves) * P.n * 8);
   // (allocated behind everything the wave count was sized for: the count -- hence the float64 summation order -- is that of round 2)
   L.ord_stride = ge_align16(2 * P.n) + ge_align16(2 * (P.n + 2));

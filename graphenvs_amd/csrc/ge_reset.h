@@ -1689,7 +1689,7 @@ GE_DEV void ge_finish_item(const GeParams &P, const GeRun &run, int env) {
 // RAGGED (multi-class engine): P is the engine-wide parameter block (B = all slots; queue, seed[], episode[], mt_state are global
 // arrays in slot order) and every workgroup looks up the class of its slot: R.classes[class] is that class's uniform sub-engine.
 template <int ENV, bool RAGGED>
-GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, GeRagged R, const uint32_t *seeds, GeRun run, GeInject inj, int nseed) {
+GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, GeRagged R, const uint32_t *seeds, GeRun run, GeInject inj, int nseed, int bucket) {
   int *pre = (int *)(ge_dyn_smem() + P.lds.pre);  // overlays the MT19937 scratch: rebuilt before every lookup
   if (ge_bid() == 0 && ge_tid() == 0) P.buf.work_count[0] = 0;  // fallback list of the feature fast path
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
@@ -1727,6 +1727,9 @@ GE_KERNEL_LB(GE_RESET_THREADS, GE_RESET_WAVES_PER_SIMD) ge_k_reset(GeParams P, G
     }
     if constexpr (RAGGED) {
       const int cls = (int)ge_uniform_u32((uint32_t)R.slot_class[env]);
+      // one launch per LDS bucket of size classes (bucket >= 0): the dynamic LDS of this launch -- hence the workgroups a CU holds --
+      // is sized for the bucket's largest class, not the engine's; the slots of other buckets are left to their launch
+      if (bucket >= 0 && R.classes[cls].bucket != bucket) continue;  // (uniform over the workgroup)
       const int lo = R.class_start[cls];
       ge_reset_env<ENV>(R.classes[cls], env - lo, seeds ? seeds + lo : seeds, run, inj);
     } else {

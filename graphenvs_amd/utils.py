@@ -30,16 +30,21 @@ def vectorize_graph(graph):
 
 
 def devectorize_graph(vector, env_id, **kwargs):
-    """utils.py:14-23: [bs, L] -> x [bs,n,F], edge_features [bs,2m,Fe], edge_index [bs,2m,2] (long)."""
-    bs = vector.shape[0]
-    node_f, edge_f, _ = get_env_info(env_id)
-    p1 = kwargs["n_nodes"] * node_f
-    p2 = p1 + 2 * kwargs["n_edges"] * edge_f
-    x = vector[:, :p1].reshape(bs, kwargs["n_nodes"], node_f)
-    edge_features = vector[:, p1:p2].reshape(bs, 2 * kwargs["n_edges"], edge_f)
-    edge_index = vector[:, p2:].reshape(bs, 2 * kwargs["n_edges"], 2)
-    edge_index = edge_index.long() if torch.is_tensor(edge_index) else edge_index.astype(np.int64)
-    return x, edge_features, edge_index
+    """Inverse of vectorize_graph for a batch of flat observations (the reference's utils.devectorize_graph, utils.py:14-23):
+    ``vector`` [B, n*F + E*Fe + 2E] -> node features [B, n, F], edge features [B, E, Fe], edge_links [B, E, 2] as int64,
+    with E = 2 * n_edges directed edges.  Works on torch tensors and numpy arrays alike; the outputs are views where possible."""
+    n, E = int(kwargs["n_nodes"]), 2 * int(kwargs["n_edges"])
+    F, Fe, _ = get_env_info(env_id)
+    sections = (n * F, E * Fe, 2 * E)              # the three pieces of the flat layout, in order
+    assert vector.shape[-1] == sum(sections), "flat observation length does not match n_nodes / n_edges of this env id"
+    batch = vector.shape[0]
+    if torch.is_tensor(vector):
+        nodes, edges, links = torch.split(vector, sections, dim=1)
+        links = links.to(torch.int64)
+    else:
+        nodes, edges, links = np.split(np.asarray(vector), np.cumsum(sections)[:-1], axis=1)
+        links = links.astype(np.int64)
+    return nodes.reshape(batch, n, F), edges.reshape(batch, E, Fe), links.reshape(batch, E, 2)
 
 
 def to_pyg_graph(x, edge_features, edge_index):
