@@ -157,7 +157,10 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
   P.node_id_base = cfg->node_id_base;
   P.edge_row_stride = cfg->edge_row_stride > 0 ? cfg->edge_row_stride : (int64_t)cfg->num_envs * 2 * m;
-  P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= 256) ? 1 : 0;  // nibble matrix of n*n/2 bytes <= 32 KiB
+#ifndef GE_NP_EARLY_MAX
+#define GE_NP_EARLY_MAX 256  // (a test build lowers it to run the late path, ge_np_draws_edges, on small graphs)
+#endif
+  P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= GE_NP_EARLY_MAX) ? 1 : 0;  // nibble matrix of n*n/2 bytes <= 32 KiB
   // few slots regenerate per step when graphs are large (long episodes): 8 workgroups share a slot's sources.  The number of
   // parts fixes the order in which a node's float64 betweenness is added up, so it depends on the geometry only, not on the
   // batch size (a shard of a batch must reproduce the unsharded run bit for bit); only a partial-sum scratch beyond 16 GiB

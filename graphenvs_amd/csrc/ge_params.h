@@ -156,6 +156,9 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   const int shared = o + 1024 + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
   L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
   int waves = (budget - shared) / (per_wave > 0 ? per_wave : 1);
+  // a graph so large that half a CU's LDS holds fewer than four waves runs one workgroup per CU with as many as fit all of it
+  // (n = 512: one wave per CU became four)
+  if (waves < 4 && budget < 160 * 1024 - 2048) waves = (160 * 1024 - 2048 - shared) / (per_wave > 0 ? per_wave : 1);
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
   if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here

@@ -326,6 +326,91 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
   ge_wave_sync();  // rounds only read the state and add into their sink: one ordering point at the end
 }
 
+// randint(3, 10, size=(n, n)) when the n x n matrix does not fit LDS (n > 256): only the cells delay[u, v], u < v, of the m edges are
+// ever read (shortest_path.py:60,66-67), but the stream has to be consumed to its end.  So the scan only COUNTS: per 64 raw words
+// one tempering, one ballot, one popcount -- and the accepted draw whose number is the next wanted cell (cells in ascending order
+// in `tcell`, built from the adjacency bit rows) is fished out of its chunk when the running count passes it: about one chunk in
+// three at n = 512.  (The draw-by-draw form tested every accepted draw against the adjacency matrix: a division and an LDS read per
+// draw, 262 144 draws per slot at n = 512.)  Needs the topology: c.abits, c.rowptr; uses c.elist (free once the CSR is built) for the
+// wanted cells and c.dist for the per-row offsets.  One wave.
+GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
+  const int n = P.n, W = P.W, m = P.m, total = n * n;
+  const uint64_t below = (1ull << lane) - 1ull;
+  // wanted cells, ascending: edge (u, v), u < v, is number up[u] + |{w in N(u): u < w < v}| where up[u] counts the edges of smaller rows
+  uint32_t *tcell = c.elist;
+  {
+    int carry = 0;
+    for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
+      const int u = k0 + lane; int d = 0;
+      if (u < n) for (int w = u >> 6; w < W; w++) { uint64_t b = c.abits[u * W + w]; if (w == (u >> 6)) b &= ~((2ull << (u & 63)) - 1ull); d += ge_popc64(b); }
+      const int incl = ge_wave_incl_scan(d, lane);
+      if (u < n) c.dist[u] = carry + incl - d;
+      carry += ge_shfl_i32(incl, GE_WAVE - 1);
+    }
+    ge_wave_sync();
+    for (int u = lane; u < n; u += GE_WAVE) {
+      int t = c.dist[u];
+      for (int w = u >> 6; w < W; w++) {
+        uint64_t b = c.abits[u * W + w]; if (w == (u >> 6)) b &= ~((2ull << (u & 63)) - 1ull);
+        for (; b; b &= b - 1) tcell[t++] = (uint32_t)(u * n + w * 64 + ge_ctz64(b));
+      }
+    }
+    ge_wave_sync();
+  }
+  int base = 0, t = 0;
+  uint32_t next = m > 0 ? tcell[0] : 0xffffffffu;
+  // the accepted draw number `next - base` of a chunk (accepted lanes `bal`, this lane's value `val`) is delay[u, v]
+  auto take = [&](uint32_t val, uint64_t bal, int cnt) {
+    while (next - (uint32_t)base < (uint32_t)cnt) {  // (wave-uniform)
+      const int r = (int)(next - (uint32_t)base);
+      if (((bal >> lane) & 1ull) && ge_popc64(bal & below) == r) {
+        const int u = (int)(next / (uint32_t)n), v = (int)(next - (uint32_t)u * (uint32_t)n);
+        const uint8_t code = (uint8_t)(3u + val);
+        c.wsort[ge_sorted_pos(c, W, u, v)] = code; c.wsort[ge_sorted_pos(c, W, v, u)] = code;
+      }
+      t++; next = t < m ? tcell[t] : 0xffffffffu;
+    }
+  };
+  while (base < total) {
+    if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+    if (GE_MT_N - nppos >= 4 * GE_WAVE) {
+      uint32_t val[4]; uint64_t bal[4]; int cnt[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) val[k] = ge_temper(mt[nppos + GE_WAVE * k + lane]) & 7u;
+      int tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { bal[k] = ge_ballot(val[k] < 7u); cnt[k] = ge_popc64(bal[k]); tot += cnt[k]; }
+      if (base + tot < total) {  // wave-uniform: the four chunks cannot end the sequence
+        if (next - (uint32_t)base < (uint32_t)tot) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) { take(val[k], bal[k], cnt[k]); base += cnt[k]; }
+        } else base += tot;
+        nppos += 4 * GE_WAVE;
+        continue;
+      }
+    }
+    {
+      const int p = nppos + lane; const bool valid = p < GE_MT_N;
+      const uint32_t val = valid ? (ge_temper(mt[p]) & 7u) : 8u;
+      const bool acc = valid && val < 7u;
+      uint64_t bal = ge_ballot(acc);
+      int nacc = ge_popc64(bal);
+      if (base + nacc >= total) {  // the stream stops right after the last needed accepted draw
+        const int need = total - base - 1;
+        const int last = ge_ctz64(ge_ballot(acc && ge_popc64(bal & below) == need));
+        bal &= (last >= 63) ? ~0ull : ((2ull << last) - 1ull); nacc = need + 1;
+        take(val, bal, nacc);
+        nppos += last + 1; base = total;
+      } else {
+        take(val, bal, nacc);
+        base += nacc;
+        nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
+      }
+    }
+  }
+  ge_wave_sync();
+}
+
 // first `need` entries of legacy numpy permutation(pn) into c.perm (np.random.choice(pn, k, replace=False) is its first k entries)
 GE_DEV void ge_np_terminals(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane, int pn, int need) {
   // Fisher-Yates from the top: for i = pn-1 .. 1: j_i = interval(i) (masked rejection), swap(a[i], a[j_i]).  Only the first
@@ -1238,7 +1323,7 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, co
       for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = P.weighted ? (int)((const uint8_t *)c.wm)[v] : 10;
     } else if (P.weighted && matrix_w) {  // n too large for the dense matrix: draw now, codes land by rank
       int nppos = pos0(1);
-      ge_np_draws(P, c, c.mt2, nppos, n * n, lane, 2);
+      ge_np_draws_edges(P, c, c.mt2, nppos, lane);
       if (t == GE_DISTRIBUTION_CENTER) ge_np_draws(P, c, c.mt2, nppos, n, lane, 3);
       if (t == GE_MULTICAST_ROUTING) ge_np_multicast_tail(P, c, c.mt2, nppos, lane);
       else ge_np_terminals(P, c, c.mt2, nppos, lane, n, P.T);

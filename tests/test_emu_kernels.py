@@ -152,6 +152,14 @@ def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep():
         gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
 
+def test_emulated_late_numpy_draws_of_large_graphs():
+    """-DGE_NP_EARLY_MAX=8: graphs above 8 nodes take the path of n > 256 -- the delay matrix is not materialised, the draw scan
+    only counts and picks out the cells of the edges (ge_np_draws_edges)."""
+    lib = build_emu.load(extra=["-DGE_NP_EARLY_MAX=8"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_late.so"))
+    for name in ["sp_n10_m20_eval", "sp_n33_m70", "st_n10_m20_d3_eval", "mc_n10_m20_p4_eval", "dc_n10_m20_p2", "lp_n10_m20_p1"]:
+        gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
+
+
 def test_emulated_dense_rows_use_the_scode_fallback(emu):
     """degree > 16: the nibble-packed node record cannot hold the row, the step falls back to row_ptr + scode."""
     import oracle
