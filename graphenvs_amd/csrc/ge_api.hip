@@ -333,6 +333,10 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
     if (rc == GE_OK && (cfgs[c].env_index_base != cfgs[0].env_index_base + start[c] || bufs[c].seed != bufs[0].seed + start[c] ||
                         bufs[c].episode != bufs[0].episode + start[c] || bufs[c].mt_state != bufs[0].mt_state + (int64_t)start[c] * GE_SEED_DEPTH * 2 * GE_MT_N))
       rc = fail(GE_E_BADARG, "classes follow one another in slot order: env_index_base, seed, episode and mt_state of class c start at its first global slot");
+    // the engine-wide kernels take the queues and the work lists from class 0 and index slot_rec by global slot through the class's pointer
+    if (rc == GE_OK && (bufs[c].reset_list != bufs[0].reset_list || bufs[c].reset_count != bufs[0].reset_count || bufs[c].work_list != bufs[0].work_list ||
+                        bufs[c].work_count != bufs[0].work_count || bufs[c].slot_rec != bufs[0].slot_rec + 2 * (int64_t)start[c]))
+      rc = fail(GE_E_BADARG, "reset_list, reset_count, work_list and work_count are engine-wide (the same pointers in every class), and slot_rec of class c starts at its first global slot");
     if (rc != GE_OK) { delete e; return rc; }
     C.buf = bufs[c];
     start[c + 1] = start[c] + cfgs[c].num_envs;

@@ -280,6 +280,10 @@ GE_HOSTDEV int ge_f64_pre_off(int E, int tsp, int nblk) { return ge_f64_bytes(E,
 #ifndef GE_F64_K
 #define GE_F64_K 3   // nodes of a level a quad handles per walk iteration (measured on the headline config: 2: 248 us, 3: 242 us, 4: 244 us)
 #endif
+#ifndef GE_F64_ABL
+#define GE_F64_ABL 0  // diagnostic ablation bits (tools/f64_phase.py; the results are wrong by construction): 1 forward walk, 2 backward walk, 4 pagerank
+                      // iterations, 8 clustering, 16 betweenness reduction; 0 when shipped
+#endif
 #define GE_F64_WALKERS (64 * GE_F64_QL)
 #define GE_F64_THREADS (GE_F64_WALKERS + 64)
 #define GE_F64_SLICE (64 / GE_F64_QL)  // nodes per lane slice
@@ -331,7 +335,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   GE_STAMP_T0(24);
   static_assert(GE_F64_QL == 4, "the walk keeps the visited / next-level sets as 16-bit slices, one per lane of a quad");
   const uint16_t *const adj_mine = (const uint16_t *)c.abits + q;  // this lane's 16 columns of an adjacency row: adj_mine[4 u]
-  if (walker) {
+  if (walker && !(GE_F64_ABL & 1)) {
     // the lane only ever pushes to the nodes of its own slice, so it keeps just that slice of the visited set and of the level being
     // discovered (one 32-bit operation where the whole sets took two); the quad assembles the whole next level once per level
     uint64_t cur = 1ull << s;
@@ -382,7 +386,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   double clus = 0.0, x = 0.0;
   if (node_wave) {  // concurrent with the walkers' forward pass
   // clustering (directed formula on the symmetric graph)
-  if (live) {
+  if (live && !(GE_F64_ABL & 8)) {
     int64_t common = 0;
     for (uint64_t r = adj; r; r &= r - 1) common += ge_popc64(adj & c.abits[ge_ctz64(r)]);
     const int64_t t8 = 8 * common, dt = 2 * (int64_t)deg, db = deg;
@@ -405,7 +409,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   uint32_t nb4[4] = {0u, 0u, 0u, 0u}; uint64_t rest = adj;
   { int k = 0; for (; rest && k < 16; rest &= rest - 1, k++) nb4[k >> 2] |= (uint32_t)ge_ctz64(rest) << (8 * (k & 3)); }
   bool conv = false;
-  for (int it = 0; it < 100 && !conv; it++) {
+  for (int it = 0; it < ((GE_F64_ABL & 4) ? 1 : 100) && !conv; it++) {
     c.x[lane] = x; c.y[lane] = sinv * x;  // unweighted: data'[j->i] * x[j] is the same product for every i
     ge_wave_sync();
     double dsum = 0.0;
@@ -435,7 +439,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   GE_STAMP(13);
   GE_STAMP_T0(25);
   // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
-  if (walker && !ovf) {
+  if (walker && !ovf && !(GE_F64_ABL & 2)) {
     int d = D;
     uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
     uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
@@ -496,7 +500,7 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   if (node_wave) {  // betweenness / closeness reduction and the write, one lane per node
   // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
   double bc = 0.0;
-  if (live) {
+  if (live && !(GE_F64_ABL & 16)) {
     for (int src = 0; src < n; src++) if (src != lane) bc += (double)c.sig[lane * GE_F64_SS + src] * c.del[lane * GE_F64_SD + src];  // delta = sigma * S
     if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
   }

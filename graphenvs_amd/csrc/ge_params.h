@@ -158,7 +158,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   int waves = (budget - shared) / (per_wave > 0 ? per_wave : 1);
   // a graph so large that half a CU's LDS holds fewer than four waves runs one workgroup per CU with as many as fit all of it
   // (n = 512: one wave per CU became four)
-  if (waves < 4 && budget < 160 * 1024 - 2048) waves = (160 * 1024 - 2048 - shared) / (per_wave > 0 ? per_wave : 1);
+  if (waves < 4 && budget < 160 * 1024 - 2048) waves = (160 * 1024 - 2048 - shared) / (per_wave + ge_align16(2 * P.n) + ge_align16(2 * (P.n + 2)) + 16);  // (with the order lists)
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
   if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here

@@ -243,7 +243,7 @@ struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; co
 // Diagnostic build only (-DGE_STAMPS, never shipped): 100 MHz timestamps of slot 0's reset phases.
 #if defined(GE_STAMPS) && !defined(GE_EMU)
 __device__ unsigned long long ge_stamp_buf[32];
-#define GE_STAMP(k) do { if (lane == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
+#define GE_STAMP(k) do { if (lane == 0 && env == 0) { ge_stamp_buf[k] = wall_clock64(); if ((k) == 11) ge_stamp_buf[30] = clock64(); if ((k) == 17) ge_stamp_buf[31] = clock64(); } } while (0)  // 30 / 31: the shader clock (s_memtime) at the ends of the n <= 64 feature kernel's slot 0
 #define GE_STAMP_T0(k) do { if (tid == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
 #elif defined(GE_STAMP_SLOTS) && !defined(GE_EMU)
 // Diagnostic build only (-DGE_STAMP_SLOTS, never shipped; tools/slot_times.py): when every slot's regeneration starts (stamp 0), when

@@ -72,7 +72,7 @@ class RaggedVectorEnv:
         self._h = h
         # episode prefetch (include/graphenvs.h, ge_attach_spares): a ragged batch is where it pays most -- every step a few slots of
         # many different sizes finish, and regenerated in place they cost the step the latency of the largest of them
-        self.prefetch = (16 if autoreset else 0) if prefetch is None else int(prefetch)
+        self.prefetch = (16 if autoreset and _library is None else 0) if prefetch is None else int(prefetch)
         self.spare = None
         if self.prefetch and autoreset:
             self._attach_spares()

@@ -250,7 +250,9 @@ class VectorGraphEnv(_VectorBase):
         # image, `prefetch` steps' worth of finished slots per launch, and moved in by one copy when the slot finishes.  Same outputs
         # with and without; it pays where few slots finish per step (long episodes, large graphs), where a regeneration in place
         # makes the whole step wait for the latency of a few slots.  None = the engine's choice for this env id and size, 0 = off.
-        self.prefetch = self.default_prefetch(env_id, self.n, self.num_envs) if prefetch is None else int(prefetch)
+        if prefetch is None:  # (the CPU sanitizer harness runs without it unless a test asks: it only doubles the work of a reset there)
+            prefetch = self.default_prefetch(env_id, self.n, self.num_envs) if _library is None else 0
+        self.prefetch = int(prefetch)
         if not self.autoreset or self.continue_streams:
             self.prefetch = 0
         self.spare = None
@@ -276,8 +278,19 @@ class VectorGraphEnv(_VectorBase):
 
     @staticmethod
     def default_prefetch(env_id, n, num_envs):
-        """refill period chosen when the caller does not say (0 = regenerate in place): see DESIGN.md, "Episode prefetch" """
-        return 0
+        """refill period chosen when the caller does not say (0 = regenerate in place).  Prefetch pays when FEW slots finish per
+        step -- a regeneration in place then costs the whole step the latency of those few -- and loses when thousands do (the
+        reset kernels already fill the chip; the copy and the slots that finish twice inside a period are pure overhead).  The
+        estimate: slots / a typical episode length under a random policy (measured, profiles/README.md round 3)."""
+        length = {"ShortestPath-v0": 0.39 * n, "LongestPath-v0": 0.39 * n, "SteinerTree-v0": 0.8 * n, "MulticastRouting-v0": 0.5 * n,
+                  "MaxIndependentSet-v0": 1.0 * n, "DensestSubgraph-v0": 0.36 * n, "DistributionCenter-v0": 6.0,
+                  "PerishableProductDelivery-v0": 80.0 * n}.get(env_id)
+        if length is None:  # TSP: every slot of a batch finishes in the same step -- one burst per episode, nothing to batch
+            return 0
+        per_step = num_envs / max(length, 1.0)
+        if per_step >= 600:
+            return 0
+        return int(min(128, max(8, 8192 / max(per_step, 1.0))))
 
     def _image_tensors(self, views=None):
         """a second set of the per-slot slabs (ge_spares.image); `views`: slabs given by the caller (multi-class engine)"""

@@ -101,6 +101,13 @@ CASES = {
     "mc_n8_m28_complete_p4_eval": ("MulticastRouting-v0", dict(n_nodes=8, n_edges=28, n_dests=3, is_eval_env=True), list(range(6))),
     "dc_n8_m28_complete_dist0p6": ("DistributionCenter-v0", dict(n_nodes=8, n_edges=28, max_distance=0.6, target_count=3), list(range(6))),
     "mc_n300_m900_p3_d4_eval": ("MulticastRouting-v0", dict(n_nodes=300, n_edges=900, n_dests=4, parenting=3, is_eval_env=True), [0]),
+    # round 3: the heavy is_eval_env baselines at sizes where the restated dict / set iteration orders do real work on the device
+    # (the engine and the C oracle share that source text, so these reference values -- not the oracle -- are their pin)
+    "st_n256_m1024_d8_eval": ("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8, is_eval_env=True), [0]),
+    "st_n64_m192_d8_eval": ("SteinerTree-v0", dict(n_nodes=64, n_edges=192, n_dests=8, is_eval_env=True), [0, 1, 2]),
+    "mis_n64_m192_unweighted_eval": ("MaxIndependentSet-v0", dict(n_nodes=64, n_edges=192, weighted=False, is_eval_env=True), [0, 1, 2, 3]),
+    "mis_n200_m600_unweighted_eval": ("MaxIndependentSet-v0", dict(n_nodes=200, n_edges=600, weighted=False, is_eval_env=True), [0]),
+    "tsp_n64_m400_p1_eval": ("TSP-v0", dict(n_nodes=64, n_edges=400, parenting=1, is_eval_env=True), [0]),
 }
 
 POLICIES = ("first", "rand")
