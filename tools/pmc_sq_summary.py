@@ -16,18 +16,23 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recu
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "ge_k" in k: dur.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 SIMDS = 256 * 4
+# Cycles of a dispatch = its duration in the kernel trace x the shader clock measured INSIDE a kernel under this load (s_memtime against
+# s_memrealtime, tools/phase_stamps.py -> profiles/r03_phase_stamps.txt: 2.22-2.40 GHz).  GRBM_GUI_ACTIVE / 8 reads high on dispatches
+# shorter than ~0.3 ms (MI355X_MICROARCH.md) -- round 2's summaries derived "clocks" of 2.5-4.7 GHz from it and understated valu_busy.
+CLOCK_GHZ = float(os.environ.get("GE_SHADER_CLOCK_GHZ", "2.25"))
 out = {"_method": "rocprofv3 --pmc, separate passes with --kernel-trace only (MI355X_MICROARCH.md: rocprofv3 PMC slots); per-launch medians. "
                   "SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs. "
-                  "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8); lds_busy likewise per 256 CUs; "
+                  "kernel_cycles = median duration (kernel trace) x shader clock measured in-kernel (GE_SHADER_CLOCK_GHZ, default 2.25); "
+                  "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * kernel_cycles); lds_busy likewise per 256 CUs; "
                   "wave_share_* = share of SQ_WAVE_CYCLES a wave spends issuing VALU / LDS / waiting."}
 for k, cs in sorted(acc.items()):
     m = {c: statistics.median(v) for c, v in cs.items()}
     d = {"launches": max(len(v) for v in cs.values()), "counters": m}
     if k in dur: d["median_us"] = statistics.median(dur[k])
-    cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    cyc = d.get("median_us", 0) * CLOCK_GHZ * 1e3
     if cyc > 0:
         d["kernel_cycles"] = cyc
-        if "median_us" in d: d["clock_ghz"] = cyc / d["median_us"] / 1e3
+        d["clock_ghz"] = CLOCK_GHZ
     wc = m.get("SQ_WAVE_CYCLES", 0)
     if wc > 0:
         for name, c in (("valu", "SQ_ACTIVE_INST_VALU"), ("lds", "SQ_ACTIVE_INST_LDS"), ("scalar", "SQ_ACTIVE_INST_SCA"), ("any_inst", "SQ_ACTIVE_INST_ANY"),
