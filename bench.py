@@ -31,7 +31,7 @@ SETTLE = 128           # untimed steps in front of the warm-up: > 2 x the longes
 # BASELINE.json configs that fit one GPU.  algo_bytes: SURVEY.md 8(d), canonical 32-bit CSR + byte mask, per env-step.
 CONFIGS = {
     "c2": dict(env_id="ShortestPath-v0", kw=dict(n_nodes=64, n_edges=192), envs=65536, algo_bytes=200,
-               kernel="ge_k_step_path64<true> (fused device policy + step)",
+               kernel="ge_k_step_path64<true, false> (fused device policy + step)",
                metric="env-steps/sec (whole node), ShortestPath-v0 n=64 m=192 batch=65536, 1/2/4/8 GPU",  # BASELINE.json's metric, verbatim
                workload="ShortestPath-v0 n_nodes=64 n_edges=192 weighted"),
     "c3": dict(env_id="TSP-v0", kw=dict(n_nodes=128, n_edges=8128, parenting=1), envs=16384, algo_bytes=1700,
@@ -137,12 +137,22 @@ def main():
     # per-kernel time, HIP events on the launch stream.  (1) every launch of the real loop bracketed by its own event
     # pair (carries ~3 us of event overhead per bracket); (2) the step kernel alone (step_kernel_us), the figure that
     # agrees with rocprofv3's kernel trace (profiles/) and is used for the roofline.
-    tm = env.timed_rollout(args.steps, policy_seed=1)
     # the step kernel inside the real loop (one HIP-event pair per launch on the launch stream, `args.steps` launches, minus the bare
     # event-pair overhead): this is the figure rocprofv3's per-kernel average of the same loop agrees with, and the one the roofline
     # uses.  The back-to-back burst right after a full reset (step_kernel_us) is a few percent faster -- warm caches, nothing between
     # the launches -- and is reported beside it.
-    pair_us = sorted(env.timed_step_burst_raw_ms(0) for _ in range(9))[4] * 1e3
+    # What one event pair adds when a kernel sits between the two events is NOT the time of an empty pair (part of the events'
+    # own latency then overlaps the kernel): it is calibrated on the kernel itself -- five launches in five pairs against five
+    # launches in one pair, same state, right after a reset: (sum of singles - burst) / 4.
+    ovh = []
+    for rep_ in range(7):
+        env.reset(seed=3000 + rep_)
+        singles = sum(env.timed_step_burst_raw_ms(1, policy_seed=2) for _ in range(5))
+        env.reset(seed=3000 + rep_)
+        ovh.append((singles - env.timed_step_burst_raw_ms(5, policy_seed=2)) * 1e3 / 4)
+    pair_us = sorted(ovh)[len(ovh) // 2]
+    env.reset(seed=0); env.random_rollout(settle, policy_seed=1)  # back in the steady state of the loop
+    tm = env.timed_rollout(args.steps, policy_seed=1)
     loop_us = tm["step_ms"] * 1e3 / args.steps - pair_us
     burst_us = step_kernel_us(env)
     step_us = loop_us
@@ -178,7 +188,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": prof_src,
                      "algorithmic_bytes_per_launch": algo * B, "avg_launch_us": step_us,
-                     "avg_launch_us_method": "HIP events around every launch of the timed loop, minus the bare event-pair overhead (%.2f us)" % pair_us,
+                     "avg_launch_us_method": "HIP events around every launch of the timed loop, minus what an event pair adds around this kernel (%.2f us: five launches in five pairs against five in one pair)" % pair_us,
                      "avg_launch_us_burst": burst_us, "kernel": cfg["kernel"]},
         "kernel_ms_per_vector_step": {"step": tm["step_ms"] / args.steps, "autoreset": tm["reset_ms"] / args.steps,
                                       "policy": tm["policy_ms"] / args.steps},

@@ -688,7 +688,8 @@ static bool prunes(const ge_engine *e) { return (e->P.env_type == GE_LONGEST_PAT
 #define GE_LAUNCH_STEP(SAMPLE, actions_arg, seed_arg)                                                                                   \
   do {                                                                                                                                  \
     if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, true, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
-    else if (path64(e)) GE_LAUNCH(ge_k_step_path64<SAMPLE>, grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
+    else if (path64(e) && e->spares) GE_LAUNCH((ge_k_step_path64<SAMPLE, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
+    else if (path64(e)) GE_LAUNCH((ge_k_step_path64<SAMPLE, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
     else if (edge_quad(e) && e->P.env_type == GE_STEINER_TREE) GE_LAUNCH((ge_k_step_edge<GE_STEINER_TREE, SAMPLE>), grid, GE_EDGE_THREADS, ge_edge_lds_bytes(e->P.AW, e->P.W), stream, e->P, actions_arg, seed_arg); \
     else if (edge_quad(e)) GE_LAUNCH((ge_k_step_edge<GE_MULTICAST_ROUTING, SAMPLE>), grid, GE_EDGE_THREADS, ge_edge_lds_bytes(e->P.AW, e->P.W), stream, e->P, actions_arg, seed_arg); \
     else if (prunes(e) && e->P.env_type == GE_TSP) GE_LAUNCH((ge_k_step<GE_TSP, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
@@ -878,7 +879,7 @@ extern "C" int ge_debug_occupancy(ge_engine *e, int *out4) {
   GE_FOR_ENV(e->P.env_type, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (ge_k_reset<ENV, false>), GE_RESET_THREADS, e->lds_bytes));
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ge_k_features64<false>, GE_F64_THREADS, e->feat_lds);
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ge_k_features<false>, GE_WAVE * e->P.ldsf.waves, e->P.ldsf.total);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, ge_k_step_path64<true>, GE_STEP_BLOCK, step_lds(e));
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, (ge_k_step_path64<true, false>), GE_STEP_BLOCK, step_lds(e));
   out4[0] = a; out4[1] = b; out4[2] = c; out4[3] = d;
   return GE_OK;
 }

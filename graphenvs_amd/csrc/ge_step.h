@@ -34,7 +34,21 @@ GE_DEV uint64_t ge_rec_make(int head, int status, int aux, uint64_t tstep) {
 // reset_count[workgroup]: no device-scope atomics, deterministic order.  Collective.
 // With spares attached (ge_attach_spares) a finished slot whose spare image is valid goes to the swap queue (swap_list / swap_count,
 // same layout) instead: `swap` says which.  wcnt: 2 ints per wave of the workgroup.
+// SPARES = false: the engine has none (a kernel instantiated so carries none of the second queue's work).
+template <bool SPARES = true>
 GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int tid, bool want, bool swap = false) {
+  if constexpr (!SPARES) {
+    const uint64_t b = ge_ballot(want);
+    const int lane = tid & 63, wave = tid >> 6, nw = ge_bdim() >> 6;
+    const int rank = ge_popc64(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = ge_popc64(b);
+    ge_sync();
+    int off = 0;
+    for (int w = 0; w < wave; w++) off += wcnt[w];
+    if (want) P.buf.reset_list[i0 + off + rank] = i;
+    if (tid == 0) { int tot = 0; for (int w = 0; w < nw; w++) tot += wcnt[w]; P.buf.reset_count[ge_bid()] = tot; }
+    return;
+  }
   const bool wr = want && !swap, ws = want && swap;
   const uint64_t b = ge_ballot(wr), b2 = ge_ballot(ws);
   const int lane = tid & 63, wave = tid >> 6, nw = ge_bdim() >> 6;
@@ -767,7 +781,7 @@ GE_KERNEL_LB(GE_EDGE_THREADS, 1) ge_k_step_edge(GeParams P, const int64_t *actio
 #define GE_ABL 0  // diagnostic ablation bits (tools/step_variants.py, results are wrong by construction); 0 when shipped
 #endif
 #define GE_ON(bit) (!(GE_ABL & (bit)))  // 1 x flag, 2 bool-mask bytes, 4 gather, 8 policy, 16 state stores, 64 output stores
-template <bool SAMPLE>
+template <bool SAMPLE, bool SPARES>
 GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t policy_seed) {
   const ge_buffers &G = P.buf;
   const int tid = ge_tid();
@@ -784,7 +798,8 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
     const uint64_t mb = G.mask_bits[i];
     const uint64_t vis0 = G.node_bits[i];
-    const uint8_t spare = P.spare_state ? P.spare_state[i] : (uint8_t)0;  // 1: the slot's next episode waits in its spare image
+    uint8_t spare = 0;  // 1: the slot's next episode waits in its spare image
+    if constexpr (SPARES) spare = P.spare_state[i];
     const int head = (int)(rec.y & 63ull), st = ge_rec_status(rec.y), dest = ge_rec_aux(rec.y);
     const uint64_t ts = ge_rec_tstep(rec.y);
     const double cost0 = ge_u64_as_f64(rec.x);
@@ -864,7 +879,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
       if (GE_ON(16)) G.node_bits[i] = vis;
     }
     if (wrote_mask && GE_ON(16)) G.mask_bits[i] = nm;
-    if (want_swap) P.spare_state[i] = 0;
+    if constexpr (SPARES) { if (want_swap) P.spare_state[i] = 0; }
     if (fin) {
       G.final_cost[i] = cost;
       G.final_len[i] = ge_popc64(vis0);  // every move adds one node to the visited set, which starts as {source}
@@ -872,7 +887,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     }
   }
   flag[tid] = wrote_mask ? 1 : 0;
-  ge_enqueue_reset(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, want_swap);  // contains the barrier
+  ge_enqueue_reset<SPARES>(P, (int *)(flag + ge_bdim()), i0, i, tid, want_reset, want_swap);  // contains the barrier
   int nb = P.B - i0; if (nb > ge_bdim()) nb = ge_bdim();
   if (nb <= 0 || !GE_ON(2)) return;
   uint8_t *out = G.mask + (int64_t)i0 * n;
