@@ -594,6 +594,7 @@ GE_KERNEL_LB(GE_EDGE_THREADS, 1) ge_k_step_edge(GeParams P, const int64_t *actio
   if (i < P.B) {
     const int64_t nbase = (int64_t)i * n, ebase = (int64_t)i * P.E;
     const ulonglong2 rec = ((const ulonglong2 *)G.slot_rec)[i];
+    ge_quad_sync();  // the four lanes have read the record before lane 0 may rewrite it (lockstep on the GPU; the CPU harness runs lanes one after another)
     const int st = ge_rec_status(rec.y);
     uint64_t ts = ge_rec_tstep(rec.y);
     // ---- action

@@ -108,6 +108,11 @@ CASES = {
     "mis_n64_m192_unweighted_eval": ("MaxIndependentSet-v0", dict(n_nodes=64, n_edges=192, weighted=False, is_eval_env=True), [0, 1, 2, 3]),
     "mis_n200_m600_unweighted_eval": ("MaxIndependentSet-v0", dict(n_nodes=200, n_edges=600, weighted=False, is_eval_env=True), [0]),
     "tsp_n64_m400_p1_eval": ("TSP-v0", dict(n_nodes=64, n_edges=400, parenting=1, is_eval_env=True), [0]),
+    # round 3: sizes the engine refused before (parenting >= 2 and spatial TSP above 512 nodes)
+    "lp_n600_m1800_p2": ("LongestPath-v0", dict(n_nodes=600, n_edges=1800, parenting=2), [0]),
+    "lp_n530_m1500_p3": ("LongestPath-v0", dict(n_nodes=530, n_edges=1500, parenting=3), [0]),
+    "tsp_n520_m1700_p2": ("TSP-v0", dict(n_nodes=520, n_edges=1700, parenting=2), [0]),
+    "tsp_n600_m2000_p1_spatial": ("TSP-v0", dict(n_nodes=600, n_edges=2000, parenting=1, spatial=True), [0]),
 }
 
 POLICIES = ("first", "rand")

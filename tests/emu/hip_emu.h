@@ -171,7 +171,11 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
       for (int t = q0; t < nthreads && t < q0 + kQuad; t++) if (!b.fib[t].done) { ql++; if (b.fib[t].waiting == 3) qw++; }
       if (ql && qw == ql) { for (int t = q0; t < nthreads && t < q0 + kQuad; t++) if (b.fib[t].waiting == 3) b.fib[t].waiting = 0; released = true; }
     }
-    if (!progressed && !released) die("deadlock: a barrier or wave collective was not reached by every live lane (divergent rendezvous)");
+    if (!progressed && !released) {
+      if (getenv("GE_EMU_DEBUG_DEADLOCK"))  // which lanes wait for what (1 block barrier, 2 wave collective, 3 quad rendezvous)
+        for (int t = 0; t < nthreads && t < 64; t++) if (!b.fib[t].done) fprintf(stderr, "[hip_emu] block %d lane %d waits for %d\n", bid, t, b.fib[t].waiting);
+      die("deadlock: a barrier or wave collective was not reached by every live lane (divergent rendezvous)");
+    }
   }
   // LDS overrun detector: the 64 bytes behind the requested dynamic LDS were poisoned above and must still be
   for (size_t k = smem_bytes; k < b.smem_bytes; k++)
