@@ -43,6 +43,7 @@ class GeLayout(C.Structure):
         ("F", C.c_int32), ("Fe", C.c_int32), ("A", C.c_int32), ("W", C.c_int32), ("E", C.c_int32),
         ("total_nodes", C.c_int64), ("total_edges", C.c_int64), ("obs_len", C.c_int64),
         ("reset_lds_bytes", C.c_int64), ("feat_parts", C.c_int32), ("eval_scratch_bytes", C.c_int64),
+        ("prune_scratch_words", C.c_int64),
     ]
 
 
@@ -51,7 +52,7 @@ BUFFER_FIELDS = [
     "node_bits", "target_bits", "counters", "seed", "episode", "heuristic", "mt_state", "aux_bits",
     "mask", "mask_bits", "reward", "terminated", "invalid", "solved", "final_cost", "final_heur",
     "final_len", "reset_list", "reset_count", "work_list", "work_count", "feat_scratch",
-    "node_aux", "range_bits", "cover_bits", "actions_out", "stream_state", "eval_scratch",
+    "node_aux", "range_bits", "cover_bits", "actions_out", "stream_state", "eval_scratch", "prune_scratch",
 ]
 SEED_DEPTH = 3  # GE_SEED_DEPTH
 STREAM_WORDS = 640  # GE_STREAM_WORDS

@@ -134,9 +134,7 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   if (t == GE_DISTRIBUTION_CENTER && !(cfg->max_distance >= 0.0)) return fail(GE_E_BADARG, "max_distance must be >= 0");
   if (t == GE_MULTICAST_ROUTING && (cfg->parenting < 1 || cfg->parenting > 4)) return fail(GE_E_BADARG, "Invalid parenting type (multicast_routing.py:34-35)");
   // not built yet
-  if (t == GE_TSP && cfg->spatial && n > 512) return fail(GE_E_UNSUPPORTED, "spatial TSP is built for n_nodes <= 512");
   if (t == GE_PERISHABLE_DELIVERY && n > 128) return fail(GE_E_UNSUPPORTED, "PerishableProductDelivery is built for n_nodes <= 128 (two-word node sets in the placement, Floyd-Warshall matrix in LDS)");
-  if ((t == GE_LONGEST_PATH || t == GE_TSP) && cfg->parenting >= 2 && n > 64 * GE_MAXW) return fail(GE_E_UNSUPPORTED, "parenting >= 2 is built for n_nodes <= 512");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
   const bool edge_env = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
@@ -197,6 +195,7 @@ extern "C" int ge_get_layout(const ge_config *cfg, ge_layout *out) {
   out->reset_lds_bytes = P.lds.total;
   out->feat_parts = P.feat_parts;
   out->eval_scratch_bytes = (int64_t)((uint64_t)P.B * eval_slot_bytes(P));
+  out->prune_scratch_words = ((P.env_type == GE_LONGEST_PATH || P.env_type == GE_TSP) && P.parenting >= 2 && P.W > GE_MAXW) ? (int64_t)P.B * 4 * P.W : 0;
   return GE_OK;
 }
 
@@ -228,6 +227,8 @@ static int check_buffers(const GeParams &P, const ge_buffers *bufs) {
   if (P.spatial && !bufs->sw64) return fail(GE_E_BADARG, "spatial TSP needs sw64");
   if (eval_slot_bytes(P) && !bufs->eval_scratch) return fail(GE_E_BADARG, "is_eval_env of TSP / unweighted MaxIndependentSet / SteinerTree (1 < n_dests < n - 1) needs eval_scratch (ge_layout.eval_scratch_bytes)");
   if (P.W == 1 && !bufs->node_rec) return fail(GE_E_BADARG, "n_nodes <= 64 needs node_rec");
+  if ((P.env_type == GE_LONGEST_PATH || P.env_type == GE_TSP) && P.parenting >= 2 && P.W > GE_MAXW && !bufs->prune_scratch)
+    return fail(GE_E_BADARG, "parenting >= 2 on more than 512 nodes needs prune_scratch ([B, 4, W] uint64)");
   return GE_OK;
 }
 
@@ -266,6 +267,15 @@ static int finish_create(ge_engine *e, ge_engine **out) {
     if (P.env_type == GE_STEINER_TREE) { hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_STEINER_TREE, true>), bytes); if (hr == hipSuccess) hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_STEINER_TREE, false>), bytes); }
     else { hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_MULTICAST_ROUTING, true>), bytes); if (hr == hipSuccess) hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step_edge<GE_MULTICAST_ROUTING, false>), bytes); }
     if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the edge step kernel"); }
+  }
+  // ---- thread-per-slot step kernel: its LDS stage (one node set per slot of the workgroup) passes 64 KB above 2 048 nodes
+  if (!rg && (size_t)GE_STEP_BLOCK * P.W * 8 + GE_STEP_BLOCK + 64 > 64 * 1024) {
+    const int bytes = (int)((size_t)GE_STEP_BLOCK * P.W * 8 + GE_STEP_BLOCK + 64);
+    const bool pr = (P.env_type == GE_LONGEST_PATH || P.env_type == GE_TSP) && P.parenting >= 2;
+    if (pr && P.env_type == GE_TSP) { hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step<GE_TSP, true, false, 2>), bytes); if (hr == hipSuccess) hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step<GE_TSP, false, false, 2>), bytes); }
+    else if (pr) { hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step<GE_LONGEST_PATH, true, false, 2>), bytes); if (hr == hipSuccess) hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step<GE_LONGEST_PATH, false, false, 2>), bytes); }
+    else { GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step<ENV, true, false, 0>), bytes)); if (hr == hipSuccess) GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_step<ENV, false, false, 0>), bytes)); }
+    if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the step kernel"); }
   }
   // ---- feature kernels
   e->feat_fast = any64 ? 1 : 0;  // (spatial TSP: float64 weights do not fit the fast path's LDS)
@@ -687,14 +697,16 @@ extern "C" int ge_sample_actions(ge_engine *e, uint64_t policy_seed, int64_t *ac
 static bool prunes(const ge_engine *e) { return (e->P.env_type == GE_LONGEST_PATH || e->P.env_type == GE_TSP) && e->P.parenting >= 2; }
 #define GE_LAUNCH_STEP(SAMPLE, actions_arg, seed_arg)                                                                                   \
   do {                                                                                                                                  \
-    if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, true, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
+    if (e->n_classes > 0) GE_FOR_RAGGED_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, true, 0>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
     else if (path64(e) && e->spares) GE_LAUNCH((ge_k_step_path64<SAMPLE, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
     else if (path64(e)) GE_LAUNCH((ge_k_step_path64<SAMPLE, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, actions_arg, seed_arg);  \
     else if (edge_quad(e) && e->P.env_type == GE_STEINER_TREE) GE_LAUNCH((ge_k_step_edge<GE_STEINER_TREE, SAMPLE>), grid, GE_EDGE_THREADS, ge_edge_lds_bytes(e->P.AW, e->P.W), stream, e->P, actions_arg, seed_arg); \
     else if (edge_quad(e)) GE_LAUNCH((ge_k_step_edge<GE_MULTICAST_ROUTING, SAMPLE>), grid, GE_EDGE_THREADS, ge_edge_lds_bytes(e->P.AW, e->P.W), stream, e->P, actions_arg, seed_arg); \
-    else if (prunes(e) && e->P.env_type == GE_TSP) GE_LAUNCH((ge_k_step<GE_TSP, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
-    else if (prunes(e)) GE_LAUNCH((ge_k_step<GE_LONGEST_PATH, SAMPLE, false, true>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
-    else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, false, false>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
+    else if (prunes(e) && e->P.env_type == GE_TSP && e->P.W > GE_MAXW) GE_LAUNCH((ge_k_step<GE_TSP, SAMPLE, false, 2>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
+    else if (prunes(e) && e->P.W > GE_MAXW) GE_LAUNCH((ge_k_step<GE_LONGEST_PATH, SAMPLE, false, 2>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
+    else if (prunes(e) && e->P.env_type == GE_TSP) GE_LAUNCH((ge_k_step<GE_TSP, SAMPLE, false, 1>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
+    else if (prunes(e)) GE_LAUNCH((ge_k_step<GE_LONGEST_PATH, SAMPLE, false, 1>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg); \
+    else GE_FOR_ENV(e->P.env_type, GE_LAUNCH((ge_k_step<ENV, SAMPLE, false, 0>), grid, GE_STEP_BLOCK, step_lds(e), stream, e->P, e->R, actions_arg, seed_arg)); \
   } while (0)
 
 static bool path64(const ge_engine *e);

@@ -67,15 +67,18 @@ GE_DEV void ge_enqueue_reset(const GeParams &P, int *wcnt, int i0, int i, int ti
   }
 }
 
-#define GE_MAXW 8  // parenting >= 2 walks the residual graph per thread: node sets of up to 8 words (n <= 512)
+#ifndef GE_MAXW
+#define GE_MAXW 8  // parenting >= 2 walks the residual graph per thread: node sets of up to 8 words (n <= 512) live in registers
+#endif
 
 // nodes reachable from `start` inside `alive` minus `skip` (skip < 0: none); rows = the slot's adjacency bit rows
-GE_DEV void ge_reach_thread(const uint64_t *rows, int W, const uint64_t *alive, int start, int skip, uint64_t *R) {
-  uint64_t fr[GE_MAXW];
+// FR / NX: the frontier and the next level -- registers (arrays of GE_MAXW words) or, above 64 * GE_MAXW nodes, two more sets of the
+// slot's prune_scratch
+template <class FR, class NX>
+GE_DEV void ge_reach_sets(const uint64_t *rows, int W, const uint64_t *alive, int start, int skip, uint64_t *R, FR &fr, NX &nx) {
   for (int w = 0; w < W; w++) { R[w] = 0; fr[w] = 0; }
   R[start >> 6] = fr[start >> 6] = 1ull << (start & 63);
   for (;;) {
-    uint64_t nx[GE_MAXW];
     for (int w = 0; w < W; w++) nx[w] = 0;
     for (int w = 0; w < W; w++)
       for (uint64_t f = fr[w]; f; f &= f - 1) {
@@ -90,6 +93,13 @@ GE_DEV void ge_reach_thread(const uint64_t *rows, int W, const uint64_t *alive, 
     }
     if (!any) break;
   }
+}
+GE_DEV void ge_reach_thread(const uint64_t *rows, int W, const uint64_t *alive, int start, int skip, uint64_t *R) {
+  uint64_t fr[GE_MAXW], nx[GE_MAXW];
+  ge_reach_sets(rows, W, alive, start, skip, R, fr, nx);
+}
+GE_DEV void ge_reach_thread_mem(const uint64_t *rows, int W, const uint64_t *alive, int start, int skip, uint64_t *R, uint64_t *fr, uint64_t *nx) {
+  ge_reach_sets(rows, W, alive, start, skip, R, fr, nx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -130,7 +140,9 @@ GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
 // PRUNE: parenting >= 2 of LongestPath / TSP (per-thread walks of the residual graph over node sets of up to GE_MAXW words, ~64
 // registers of scratch sets): its own instantiation, so that the plain transitions (BASELINE config 3 runs TSP with parenting 1)
 // do not carry those registers.
-template <int ENV, bool SAMPLE, bool RAGGED, bool PRUNE>
+// PRUNE = 2: the same walks for graphs above 64 * GE_MAXW nodes -- the node sets live in the slot's prune_scratch (four sets of W
+// words in global memory) instead of registers: slow, but these are graphs on which the reference itself takes seconds per step.
+template <int ENV, bool SAMPLE, bool RAGGED, int PRUNE>
 GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t policy_seed) {
   const int tid = ge_tid();
   const int i0 = ge_bid() * ge_bdim();
@@ -188,22 +200,29 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
           head_out = a;
           G.x[(nbase + a) * F + 0] = 1.f;
           uint64_t any = 0;
-          uint64_t alive[PRUNE ? GE_MAXW : 1], R[PRUNE ? GE_MAXW : 1];
+          // node sets of the walk: registers (accessed as arrays, so that they stay there), or the slot's prune_scratch (PRUNE == 2)
+          uint64_t la_[PRUNE == 1 ? GE_MAXW : 1], lr_[PRUNE == 1 ? GE_MAXW : 1];
+          uint64_t *const sc_ = (PRUNE == 2) ? G.prune_scratch + (int64_t)i * 4 * W : nullptr;
+#define alive(w) (*(PRUNE == 2 ? &sc_[w] : &la_[w]))
+#define R(w) (*(PRUNE == 2 ? &sc_[W + (w)] : &lr_[w]))
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
-            if (PRUNE && w < GE_MAXW) alive[w] = ge_full_word(n, w) & ~vb;
+            if (PRUNE == 2 || (PRUNE == 1 && w < GE_MAXW)) alive(w) = ge_full_word(n, w) & ~vb;
           }
           const bool prune = PRUNE && lp && P.parenting >= 2 && a != dest;  // longest_path.py:134-143 (dest still in alt_G)
           int n_alive = 0;
           if constexpr (PRUNE) {
-            if (prune) ge_reach_thread(G.adj_bits + nbase * W, W, alive, dest, -1, R);
-            if (lp && P.parenting == 3) for (int w = 0; w < W; w++) n_alive += ge_popc64(alive[w]);
+            if (prune) {
+              if constexpr (PRUNE == 2) ge_reach_thread_mem(G.adj_bits + nbase * W, W, sc_, dest, -1, sc_ + W, sc_ + 2 * W, sc_ + 3 * W);
+              else ge_reach_thread(G.adj_bits + nbase * W, W, la_, dest, -1, lr_);
+            }
+            if (lp && P.parenting == 3) for (int w = 0; w < W; w++) n_alive += ge_popc64(alive(w));
           }
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             uint64_t nm = (lp && P.parenting == 0) ? ge_full_word(A, w) : (G.adj_bits[(nbase + a) * W + w] & ~vb);
-            if constexpr (PRUNE) { if (prune) { nm &= R[w]; if (P.parenting == 3 && n_alive <= n / 3) nm |= alive[w]; } }
+            if constexpr (PRUNE) { if (prune) { nm &= R(w); if (P.parenting == 3 && n_alive <= n / 3) nm |= alive(w); } }
             stage[tid * WS + w] = nm; any |= nm;
           }
           wrote_mask = !(lp && P.parenting == 0);
@@ -236,12 +255,13 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
             stage[tid * WS + w] = nm; any |= nm;
           }
           if constexpr (PRUNE) if (P.parenting >= 2 && any) {  // tsp.py:181-194: a move must leave the untaken nodes (start excluded) connected
-            uint64_t alive[GE_MAXW], R[GE_MAXW];
+            uint64_t la_[PRUNE == 1 ? GE_MAXW : 1], lr_[PRUNE == 1 ? GE_MAXW : 1];
+            uint64_t *const sc_ = (PRUNE == 2) ? G.prune_scratch + (int64_t)i * 4 * W : nullptr;
             int n_alive = 0;
             for (int w = 0; w < W; w++) {
-              alive[w] = ge_full_word(n, w) & ~G.node_bits[(int64_t)i * W + w];
-              if (w == 0) alive[w] &= ~1ull;
-              n_alive += ge_popc64(alive[w]);
+              alive(w) = ge_full_word(n, w) & ~G.node_bits[(int64_t)i * W + w];
+              if (w == 0) alive(w) &= ~1ull;
+              n_alive += ge_popc64(alive(w));
             }
             any = 0;
             bool stop = false;
@@ -252,10 +272,11 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
                 if (v == start) continue;
                 if (n_alive - 1 == 0) { stop = true; break; }  // G_copy has no node left
                 int from = -1;
-                for (int w2 = 0; w2 < W && from < 0; w2++) { uint64_t r = alive[w2]; if ((v >> 6) == w2) r &= ~(1ull << (v & 63)); if (r) from = w2 * 64 + ge_ctz64(r); }
-                ge_reach_thread(G.adj_bits + nbase * W, W, alive, from, v, R);
+                for (int w2 = 0; w2 < W && from < 0; w2++) { uint64_t r = alive(w2); if ((v >> 6) == w2) r &= ~(1ull << (v & 63)); if (r) from = w2 * 64 + ge_ctz64(r); }
+                if constexpr (PRUNE == 2) ge_reach_thread_mem(G.adj_bits + nbase * W, W, sc_, from, v, sc_ + W, sc_ + 2 * W, sc_ + 3 * W);
+                else ge_reach_thread(G.adj_bits + nbase * W, W, la_, from, v, lr_);
                 int reached = 0;
-                for (int w2 = 0; w2 < W; w2++) reached += ge_popc64(R[w2]);
+                for (int w2 = 0; w2 < W; w2++) reached += ge_popc64(R(w2));
                 if (reached != n_alive - 1) nm &= ~(1ull << (v & 63));
               }
               stage[tid * WS + w] = nm; any |= nm;
@@ -265,6 +286,8 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
           if (!done && !any) { done = 1; reward -= (double)(n * 2); solved = 0; }
           break;
         }
+#undef alive
+#undef R
         case GE_STEINER_TREE: {
           if (!mbit) { invalid = 1; break; }
           acted = true;

@@ -233,6 +233,7 @@ class VectorGraphEnv(_VectorBase):
         t["actions_out"] = z((B,), torch.int64) if record_actions else None
         t["stream_state"] = z((B, 2, _lib.STREAM_WORDS), torch.int32) if self.continue_streams else None
         t["eval_scratch"] = z((lay.eval_scratch_bytes,), torch.uint8) if lay.eval_scratch_bytes else None  # TSP is_eval_env: Christofides work space
+        t["prune_scratch"] = z((lay.prune_scratch_words,), torch.int64) if lay.prune_scratch_words else None  # node sets of the residual-graph walks (registers up to 512 nodes)
         if _views:  # slabs shared with sibling engines of other geometries (RaggedVectorEnv)
             for k, v in _views.items():
                 if t[k] is None:
@@ -510,7 +511,7 @@ class VectorGraphEnv(_VectorBase):
     def state_dict(self):
         """Snapshot of every engine slab: the whole state of the batch, generator states included."""
         self._quiesce()
-        sd = {k: v.clone() for k, v in dict.items(self.t) if v is not None and k != "eval_scratch"}  # work space, not state
+        sd = {k: v.clone() for k, v in dict.items(self.t) if v is not None and k not in ("eval_scratch", "prune_scratch")}  # work space, not state
         if self.spare is not None:  # the images themselves are not state (they are regenerated); the marker says which invariant the generator ring obeys
             sd["_prefetch"] = torch.ones((), dtype=torch.int32)
         return sd

@@ -96,6 +96,7 @@ typedef struct {
   int64_t eval_scratch_bytes;  /* bytes of ge_buffers.eval_scratch: work space of the is_eval_env baselines that run as sequential
                                   programs (TSP: closure matrix + matching tables per slot; unweighted MaxIndependentSet: graph
                                   copies + set tables of clique removal); else 0 */
+  int64_t prune_scratch_words; /* uint64 words of ge_buffers.prune_scratch (num_envs x 4 x W for parenting >= 2 on more than 512 nodes); else 0 */
 } ge_layout;
 
 /* Device buffers.  B = num_envs, Nn = B*n, Ne = B*E, W = ceil(n/64).
@@ -163,6 +164,8 @@ typedef struct {
                                  when present -- what ge_reset_continue (reset(seed=None), shortest_path.py:49-52) resumes from */
   uint8_t *eval_scratch;  /* [ge_layout.eval_scratch_bytes] is_eval_env work space: TSP's Christofides baseline (tsp.py:114-117),
                                  MaxIndependentSet's clique removal (max_independent_set.py:63-67); else NULL */
+  uint64_t *prune_scratch;/* [B, 4, W] LongestPath / TSP with parenting >= 2 on graphs above 512 nodes: node sets of the residual-graph
+                                 walks of step() (longest_path.py:134-143, tsp.py:181-194), which smaller graphs keep in registers; else NULL */
 } ge_buffers;
 
 typedef struct ge_engine ge_engine;

@@ -160,6 +160,35 @@ def test_emulated_late_numpy_draws_of_large_graphs():
         gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
 
+@pytest.mark.parametrize("env_id,kw", [("LongestPath-v0", dict(n_nodes=70, n_edges=170, parenting=2)),
+                                       ("LongestPath-v0", dict(n_nodes=66, n_edges=150, parenting=3)),
+                                       ("TSP-v0", dict(n_nodes=66, n_edges=200, parenting=2))])
+def test_emulated_residual_walks_in_memory(env_id, kw):
+    """-DGE_MAXW=1: graphs above 64 nodes take the path of graphs above 512 -- the node sets of the parenting >= 2 walks of step()
+    live in prune_scratch instead of registers (longest_path.py:134-143, tsp.py:181-194)."""
+    import oracle
+    lib = build_emu.load(extra=["-DGE_MAXW=1"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_maxw1.so"))
+    B, K = 3, 45
+    env = ge.VectorGraphEnv(env_id, B, device="cpu", _library=lib, obs_mode="flat", autoreset=False, **kw)
+    assert env.t["prune_scratch"] is not None
+    env.reset(seed=4)
+    refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+    for i, r in enumerate(refs):
+        r.reset(seed=4 + i)
+    alive = [True] * B
+    for k in range(K):
+        a = env.sample_random_actions(policy_seed=6).clone().numpy()
+        _, rew, term, _, info = env.step(a)
+        for i, r in enumerate(refs):
+            if not alive[i]:
+                continue
+            _, rr, dd, _, _ = r.step(int(a[i]))
+            assert float(rew[i]) == rr and bool(term[i]) == dd, (k, i)
+            assert np.array_equal(info["mask"][i].numpy(), r.mask()), (k, i)
+            alive[i] = not dd
+    env.close()
+
+
 def test_emulated_dense_rows_use_the_scode_fallback(emu):
     """degree > 16: the nibble-packed node record cannot hold the row, the step falls back to row_ptr + scode."""
     import oracle
