@@ -81,6 +81,9 @@ static const char g_source_hash[] = "GE_SOURCE_HASH=" GE_SOURCE_HASH;  // the ma
 extern "C" const char *ge_source_hash(void) { return g_source_hash + 15; }
 
 static const int kMaxLds = 160 * 1024;
+#ifndef GE_NP_EARLY_MAX
+#define GE_NP_EARLY_MAX 256  // graphs up to this size hold the n x n delay matrix in LDS (a test build lowers it to run the late path, ge_np_draws_edges, on small graphs)
+#endif
 
 // the reset kernel is instantiated per env type (ge_k_reset<ENV>): run `stmt` with ENV bound to the runtime env type
 #define GE_FOR_ENV(env_type, stmt)                                                           \
@@ -134,7 +137,7 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   if (t == GE_DISTRIBUTION_CENTER && !(cfg->max_distance >= 0.0)) return fail(GE_E_BADARG, "max_distance must be >= 0");
   if (t == GE_MULTICAST_ROUTING && (cfg->parenting < 1 || cfg->parenting > 4)) return fail(GE_E_BADARG, "Invalid parenting type (multicast_routing.py:34-35)");
   // not built yet
-  if (t == GE_PERISHABLE_DELIVERY && n > 128) return fail(GE_E_UNSUPPORTED, "PerishableProductDelivery is built for n_nodes <= 128 (two-word node sets in the placement, Floyd-Warshall matrix in LDS)");
+  if (t == GE_PERISHABLE_DELIVERY && cfg->weighted && n > GE_NP_EARLY_MAX) return fail(GE_E_UNSUPPORTED, "weighted PerishableProductDelivery is built for n_nodes <= 256 (its placement reads the delay matrix, which lives in LDS)");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
   const bool edge_env = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);
@@ -155,9 +158,6 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   P.env_index_base = cfg->env_index_base; P.seed_stride = cfg->seed_stride;
   P.node_id_base = cfg->node_id_base;
   P.edge_row_stride = cfg->edge_row_stride > 0 ? cfg->edge_row_stride : (int64_t)cfg->num_envs * 2 * m;
-#ifndef GE_NP_EARLY_MAX
-#define GE_NP_EARLY_MAX 256  // (a test build lowers it to run the late path, ge_np_draws_edges, on small graphs)
-#endif
   P.np_early = (t == GE_TSP || t == GE_MAX_INDEPENDENT_SET || t == GE_DENSEST_SUBGRAPH || !cfg->weighted || n <= GE_NP_EARLY_MAX) ? 1 : 0;  // nibble matrix of n*n/2 bytes <= 32 KiB
   // few slots regenerate per step when graphs are large (long episodes): 8 workgroups share a slot's sources.  The number of
   // parts fixes the order in which a node's float64 betweenness is added up, so it depends on the geometry only, not on the

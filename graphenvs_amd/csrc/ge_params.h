@@ -131,7 +131,7 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
   { int need = 2 * P.n * 8, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
   L.bits = take(6 * P.W * 8);
   L.misc = take(16 * 4);
-  L.fw = (P.env_type == GE_PERISHABLE_DELIVERY) ? take(P.n * P.n * 8) : 0;
+  L.fw = (P.env_type == GE_PERISHABLE_DELIVERY && P.n <= 128) ? take(P.n * P.n * 8) : 0;  // (larger graphs: distances per pickup, ge_ppd_place_wide)
   L.dcs = (P.env_type == GE_DISTRIBUTION_CENTER && P.n <= 64) ? take(P.n * GE_DC_LANES * 8 + 64 * GE_DC_LANES) : 0;
   L.kou = (P.env_type == GE_STEINER_TREE && P.is_eval && P.n_dests > 1 && P.n_dests < P.n - 1) ? take(2 * P.n * P.W * 8 + P.T * 16) : 0;
   // the queue prefix is only needed while a workgroup looks up its slot: it overlays the scratch that follows

@@ -836,6 +836,37 @@ GE_DEV int ge_select2(uint64_t w0, uint64_t w1, int k) {
   return base + ge_ctz64(w);
 }
 
+#ifndef GE_PPD_WIDE_ABOVE
+#define GE_PPD_WIDE_ABOVE 128  // (a test build lowers it to run the placement of large graphs on small ones)
+#endif
+// ---- PerishableProductDelivery above 128 nodes: no n x n matrix in LDS and node sets of W words.
+// Distances from `p` to every node into dist[] (LDS), straight from the adjacency bit rows and the nibble matrix of delays (the CSR
+// does not exist yet inside the rejection loop): in-place relaxation sweeps to the least fixpoint of d[v] = min_u d[u] + delay(u, v)
+// -- float addition is monotone, so the fixpoint does not depend on the order of the relaxations.
+GE_DEV void ge_ppd_dist(const GeParams &P, const GeRctx &c, int p, double *dist, int lane) {
+  const int n = P.n, W = P.W;
+  for (int v = lane; v < n; v += GE_WAVE) dist[v] = (v == p) ? 0.0 : __builtin_inf();
+  ge_wave_sync();
+  for (;;) {
+    bool improved = false;
+    for (int v0 = 0; v0 < n; v0 += GE_WAVE) {
+      const int v = v0 + lane;
+      if (v < n) {
+        double best = dist[v];
+        for (int w = 0; w < W; w++)
+          for (uint64_t r = c.abits[v * W + w]; r; r &= r - 1) {
+            const int u = w * 64 + ge_ctz64(r);
+            const int cell = (u < v ? u : v) * n + (u < v ? v : u);
+            const double d = dist[u] + (P.weighted ? ge_wlut((int)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u)) : 1.0);
+            if (d < best) best = d;
+          }
+        if (best < dist[v]) { dist[v] = best; improved = true; }
+      }
+    }
+    ge_wave_sync();
+    if (!ge_ballot(improved)) break;
+  }
+}
 // perishable_product_delivery.py:92-108, one attempt on a connected graph whose delay matrix is in the nibble matrix:
 // delivery_time = rand() * (dt_max - dt_min) + dt_min; apsp = floyd_warshall; per product a pickup among the unused nodes
 // and a drop-off among the unused nodes closer than delivery_time + 1e-6, listed in the key order of the apsp[pickup]
@@ -911,6 +942,84 @@ GE_DEV bool ge_ppd_place(const GeParams &P, const GeRctx &c, double *D, double r
         else k -= cnt;
       }
     } else d = ge_select2(R0, R1, k - nB - nC);
+    dp[i] = d;
+  }
+  for (int j = 0; j < np_; j++) if (pk[j] < 0 || dp[j] < 0) return false;
+  return true;
+}
+
+// the k-th set bit (k from 0) of a set of W words given word by word; the caller guarantees it exists
+template <class F>
+GE_DEV int ge_select_words(int W, int k, F word) {
+  for (int w = 0; w < W; w++) {
+    uint64_t x = word(w);
+    const int cnt = ge_popc64(x);
+    if (k < cnt) { for (int j = 0; j < k; j++) x &= x - 1; return w * 64 + ge_ctz64(x); }
+    k -= cnt;
+  }
+  return -1;
+}
+// ge_ppd_place for n > 128 (same draws, same candidate orders).  The drop-off filter `apsp[pickup][v] < delivery_time + 1e-6`
+// (perishable_product_delivery.py:100-104) is evaluated on distances summed from the pickup outwards, where nx.floyd_warshall
+// associates the same path's delays in the order of its sweeps: the two can differ in the last bit of a float64, which only matters
+// for a node whose distance is within 1e-15 of the threshold (a uniformly drawn real): not observed, not excluded.
+GE_DEV bool ge_ppd_place_wide(const GeParams &P, const GeRctx &c, double rnd, int &nppos, int *pk, int *dp, double &dt_out, int lane) {
+  const int n = P.n, m = P.m, np_ = P.n_dests, W = P.W;
+  const double dt = rnd * (P.dt_max - P.dt_min) + P.dt_min;
+  dt_out = dt;
+  uint64_t *used = c.bits, *pass = c.bits + W;  // c.bits: six sets of W words, free inside the rejection loop
+  double *dist = c.sigma;
+  auto rebuild_used = [&]() {
+    ge_wave_sync();  // every lane has read the set it chose from before it is rewritten
+    if (lane < W) {
+      uint64_t u = 0;
+      for (int j = 0; j < np_; j++) {
+        if (pk[j] >= 0 && (pk[j] >> 6) == lane) u |= 1ull << (pk[j] & 63);
+        if (dp[j] >= 0 && (dp[j] >> 6) == lane) u |= 1ull << (dp[j] & 63);
+      }
+      used[lane] = u;
+    }
+    ge_wave_sync();
+  };
+  for (int i = 0; i < np_; i++) {
+    rebuild_used();
+    int nfree = 0;
+    for (int w = 0; w < W; w++) nfree += ge_popc64(ge_full_word_n(n, w) & ~used[w]);
+    const int p = ge_select_words(W, ge_np_index(c.mt2, nppos, nfree, lane), [&](int w) { return ge_full_word_n(n, w) & ~used[w]; });
+    pk[i] = p;  // replaces what a failed attempt may have left in this entry: the used set is rebuilt
+    rebuild_used();
+    ge_ppd_dist(P, c, p, dist, lane);
+    for (int w = 0; w < W; w++) {
+      const int v = w * GE_WAVE + lane;
+      const uint64_t b = ge_ballot(v < n && dist[v] < dt + 1e-6);
+      if (lane == 0) pass[w] = b & ~used[w];
+    }
+    ge_wave_sync();
+    auto nbw = [&](int w) { return c.abits[p * W + w]; };
+    auto low = [&](int w) { return w < (p >> 6) ? ~0ull : (w == (p >> 6) ? ((1ull << (p & 63)) - 1ull) : 0ull); };  // nodes below p
+    auto Bw = [&](int w) { return pass[w] & nbw(w) & low(w); };    // neighbours below p, ascending
+    auto Cw = [&](int w) { return pass[w] & nbw(w) & ~low(w); };   // neighbours above p, adjacency insertion order
+    auto Rw = [&](int w) { return pass[w] & ~nbw(w); };            // the rest, ascending (p itself is used)
+    int nB = 0, nC = 0, nR = 0;
+    for (int w = 0; w < W; w++) { nB += ge_popc64(Bw(w)); nC += ge_popc64(Cw(w)); nR += ge_popc64(Rw(w)); }
+    if (nB + nC + nR == 0) return false;
+    int k = ge_np_index(c.mt2, nppos, nB + nC + nR, lane);
+    int d;
+    if (k < nB) d = ge_select_words(W, k, Bw);
+    else if (k < nB + nC && P.complete) d = ge_select_words(W, k - nB, Cw);
+    else if (k < nB + nC) {  // the (k - nB)-th edge of p, in insertion order, whose other end is in C
+      k -= nB; d = -1;
+      for (int e0 = 0; e0 < m && d < 0; e0 += GE_WAVE) {
+        const int e = e0 + lane;
+        int other = -1;
+        if (e < m) { const uint32_t uv = c.elist[e]; const int u = (int)(uv & 0xffffu), v = (int)(uv >> 16); other = (u == p) ? v : ((v == p) ? u : -1); }
+        const bool hit = other >= 0 && ((Cw(other >> 6) >> (other & 63)) & 1ull);
+        const uint64_t H = ge_ballot(hit);
+        const int cnt = ge_popc64(H);
+        if (k < cnt) { uint64_t hh = H; for (int j = 0; j < k; j++) hh &= hh - 1; d = ge_shfl_i32(other, ge_ctz64(hh)); }
+        else k -= cnt;
+      }
+    } else d = ge_select_words(W, k - nB - nC, Rw);
     dp[i] = d;
   }
   for (int j = 0; j < np_; j++) if (pk[j] < 0 || dp[j] < 0) return false;
@@ -1177,7 +1286,8 @@ GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, co
           rnd = ((double)(int32_t)(ra >> 5) * 67108864.0 + (double)(int32_t)(rb >> 6)) / 9007199254740992.0;
         }
         ppd_attempt++;
-        ok = ge_ppd_place(P, c, (double *)(ge_dyn_smem() + P.lds.fw), rnd, ppd_pos, ppd_pk, ppd_dp, ppd_dt, lane);
+        ok = (n > GE_PPD_WIDE_ABOVE) ? ge_ppd_place_wide(P, c, rnd, ppd_pos, ppd_pk, ppd_dp, ppd_dt, lane)
+                       : ge_ppd_place(P, c, (double *)(ge_dyn_smem() + P.lds.fw), rnd, ppd_pos, ppd_pk, ppd_dp, ppd_dt, lane);
       }
       if (ok) break;
       // a rejected attempt: from here on this wave is on the launch's critical path (tools/slot_times.py: the median slot is written

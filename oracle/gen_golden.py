@@ -113,6 +113,8 @@ CASES = {
     "lp_n530_m1500_p3": ("LongestPath-v0", dict(n_nodes=530, n_edges=1500, parenting=3), [0]),
     "tsp_n520_m1700_p2": ("TSP-v0", dict(n_nodes=520, n_edges=1700, parenting=2), [0]),
     "tsp_n600_m2000_p1_spatial": ("TSP-v0", dict(n_nodes=600, n_edges=2000, parenting=1, spatial=True), [0]),
+    "ppd_n200_m600_eval": ("PerishableProductDelivery-v0", dict(n_nodes=200, n_edges=600, parenting=1, is_eval_env=True), [0, 1]),
+    "ppd_n300_m900_unweighted": ("PerishableProductDelivery-v0", dict(n_nodes=300, n_edges=900, n_products=2, weighted=False, parenting=1), [0]),
 }
 
 POLICIES = ("first", "rand")

@@ -189,6 +189,14 @@ def test_emulated_residual_walks_in_memory(env_id, kw):
     env.close()
 
 
+def test_emulated_perishable_delivery_placement_of_large_graphs():
+    """-DGE_PPD_WIDE_ABOVE=6: graphs above 6 nodes take the placement of graphs above 128 -- no Floyd-Warshall matrix in LDS,
+    distances per pickup, node sets of W words (ge_ppd_place_wide); the fixtures at n = 200 / 300 run on the GPU."""
+    lib = build_emu.load(extra=["-DGE_PPD_WIDE_ABOVE=6"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_ppdwide.so"))
+    for name in ["ppd_n8_m9_p3", "ppd_n7_m21_complete"]:  # (sparse: placement retries; complete: the closed-form candidate order)
+        gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
+
+
 def test_emulated_dense_rows_use_the_scode_fallback(emu):
     """degree > 16: the nibble-packed node record cannot hold the row, the step falls back to row_ptr + scode."""
     import oracle
