@@ -338,6 +338,7 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
   const uint64_t below = (1ull << lane) - 1ull;
   // wanted cells, ascending: edge (u, v), u < v, is number up[u] + |{w in N(u): u < w < v}| where up[u] counts the edges of smaller rows
   uint32_t *tcell = c.elist;
+  uint8_t *tcode = (uint8_t *)c.wm;  // the code of wanted cell number t (the numpy wave drew nothing into wm: no matrix at this size)
   {
     int carry = 0;
     for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
@@ -357,18 +358,19 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
     }
     ge_wave_sync();
   }
-  int base = 0, t = 0;
-  uint32_t next = m > 0 ? tcell[0] : 0xffffffffu;
-  // the accepted draw number `next - base` of a chunk (accepted lanes `bal`, this lane's value `val`) is delay[u, v]
+  // The hot loop touches no graph structure: the wanted cells are held 64 at a time in a register (lane j: cell number t0 + j, read
+  // with v_readlane), and the accepted draw that lands on one is stored by its lane as tcode[t]; the codes go to their two slots
+  // of the ascending-neighbour order afterwards, one lane per edge.
+  int base = 0, t = 0, t0 = 0;
+  uint32_t treg = lane < m ? tcell[lane] : 0xffffffffu;
+  uint32_t next = ge_readlane_u32(treg, 0);
   auto take = [&](uint32_t val, uint64_t bal, int cnt) {
     while (next - (uint32_t)base < (uint32_t)cnt) {  // (wave-uniform)
       const int r = (int)(next - (uint32_t)base);
-      if (((bal >> lane) & 1ull) && ge_popc64(bal & below) == r) {
-        const int u = (int)(next / (uint32_t)n), v = (int)(next - (uint32_t)u * (uint32_t)n);
-        const uint8_t code = (uint8_t)(3u + val);
-        c.wsort[ge_sorted_pos(c, W, u, v)] = code; c.wsort[ge_sorted_pos(c, W, v, u)] = code;
-      }
-      t++; next = t < m ? tcell[t] : 0xffffffffu;
+      if (((bal >> lane) & 1ull) && ge_popc64(bal & below) == r) tcode[t] = (uint8_t)(3u + val);
+      t++;
+      if (t - t0 == GE_WAVE) { t0 = t; treg = (t0 + lane < m) ? tcell[t0 + lane] : 0xffffffffu; }
+      next = ge_readlane_u32(treg, t - t0);
     }
   };
   while (base < total) {
@@ -407,6 +409,13 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
         nppos += (GE_MT_N - nppos < GE_WAVE) ? (GE_MT_N - nppos) : GE_WAVE;
       }
     }
+  }
+  ge_wave_sync();
+  for (int e = lane; e < m; e += GE_WAVE) {  // delay[u, v] of edge number e, to both directions
+    const uint32_t cell = tcell[e];
+    const int u = (int)(cell / (uint32_t)n), v = (int)(cell - (uint32_t)u * (uint32_t)n);
+    const uint8_t code = tcode[e];
+    c.wsort[ge_sorted_pos(c, W, u, v)] = code; c.wsort[ge_sorted_pos(c, W, v, u)] = code;
   }
   ge_wave_sync();
 }
