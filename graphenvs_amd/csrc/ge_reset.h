@@ -375,6 +375,20 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
   };
   while (base < total) {
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
+    if (nppos == 0 && total - base > GE_MT_N) {  // a whole block of 624 raw words that cannot end the sequence: ten chunks in one trip
+      uint32_t val[10]; uint64_t bal[10]; int cnt[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) { const int idx = GE_WAVE * k + lane; val[k] = idx < GE_MT_N ? (ge_temper(mt[idx]) & 7u) : 7u; }
+      int tot = 0;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { bal[k] = ge_ballot(val[k] < 7u); cnt[k] = ge_popc64(bal[k]); tot += cnt[k]; }
+      if (next - (uint32_t)base < (uint32_t)tot) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) { take(val[k], bal[k], cnt[k]); base += cnt[k]; }
+      } else base += tot;
+      nppos = GE_MT_N;
+      continue;
+    }
     if (GE_MT_N - nppos >= 4 * GE_WAVE) {
       uint32_t val[4]; uint64_t bal[4]; int cnt[4];
 #pragma unroll
