@@ -20,7 +20,7 @@ import graphenvs_amd as ge  # noqa: E402
 
 emu = build_emu.load(asan=True)
 CASES = sys.argv[1:] or ["sp_n10_m20_eval", "st_n10_m20_d3_eval", "tsp_n10_m20_p1_eval", "mis_n12_m20_unweighted_eval", "mc_n10_m20_p4_eval",
-                         "ppd_n8_m9_p3"]
+                         "ppd_n7_m21_complete"]
 for name in CASES:
     st = gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=emu, **kw), policies=("first",))
     assert st["resets"] > 0

@@ -32,6 +32,16 @@ def emu():
     return build_emu.load()
 
 
+@pytest.fixture(scope="module")
+def stress():
+    """ONE more build of the harness with every path that only large or deep graphs take forced onto small ones: the generic feature
+    kernel for slots deeper than 3 levels (-DGE_F64_LV=3), the late numpy draws of graphs above 256 nodes (-DGE_NP_EARLY_MAX=8), the
+    residual-graph walks of parenting >= 2 above 512 nodes (-DGE_MAXW=1: above 64), the placement of PerishableProductDelivery above
+    128 nodes (-DGE_PPD_WIDE_ABOVE=6)"""
+    return build_emu.load(extra=["-DGE_F64_LV=3", "-DGE_NP_EARLY_MAX=8", "-DGE_MAXW=1", "-DGE_PPD_WIDE_ABOVE=6"],
+                          out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_stress.so"))
+
+
 @pytest.mark.parametrize("name", FAST)
 def test_emulated_kernels_replay_golden(emu, name):
     case = gu.load_case(name)
@@ -136,7 +146,7 @@ def test_emulated_fused_rollout_equals_sample_then_step(emu, env_id, kw):
     a = ge.VectorGraphEnv(env_id, 70, device="cpu", _library=emu, obs_mode="flat", **kw)
     b = ge.VectorGraphEnv(env_id, 70, device="cpu", _library=emu, obs_mode="flat", **kw)
     a.reset(seed=1); b.reset(seed=1)
-    for k in range(25):
+    for k in range(15):
         a.step(a.sample_random_actions(policy_seed=4).clone())
         b.random_rollout(1, policy_seed=4)
         for key in ("reward", "terminated", "mask", "mask_bits", "head", "node_bits", "cost", "episode", "tstep", "x", "solved"):
@@ -144,18 +154,18 @@ def test_emulated_fused_rollout_equals_sample_then_step(emu, env_id, kw):
     assert int(a.t["episode"].sum()) > 0
 
 
-def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep():
+def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep(stress):
     """-DGE_F64_LV=3 forces the lane-per-source path to hand deep slots to the generic kernel."""
-    lib = build_emu.load(extra=["-DGE_F64_LV=3"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_lv3.so"))
+    lib = stress
     for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1"]:
         case = gu.load_case(name)
         gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
 
-def test_emulated_late_numpy_draws_of_large_graphs():
+def test_emulated_late_numpy_draws_of_large_graphs(stress):
     """-DGE_NP_EARLY_MAX=8: graphs above 8 nodes take the path of n > 256 -- the delay matrix is not materialised, the draw scan
     only counts and picks out the cells of the edges (ge_np_draws_edges)."""
-    lib = build_emu.load(extra=["-DGE_NP_EARLY_MAX=8"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_late.so"))
+    lib = stress
     for name in ["sp_n10_m20_eval", "sp_n33_m70", "st_n10_m20_d3_eval", "mc_n10_m20_p4_eval", "dc_n10_m20_p2", "lp_n10_m20_p1"]:
         gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
@@ -163,12 +173,12 @@ def test_emulated_late_numpy_draws_of_large_graphs():
 @pytest.mark.parametrize("env_id,kw", [("LongestPath-v0", dict(n_nodes=70, n_edges=170, parenting=2)),
                                        ("LongestPath-v0", dict(n_nodes=66, n_edges=150, parenting=3)),
                                        ("TSP-v0", dict(n_nodes=66, n_edges=200, parenting=2))])
-def test_emulated_residual_walks_in_memory(env_id, kw):
+def test_emulated_residual_walks_in_memory(stress, env_id, kw):
     """-DGE_MAXW=1: graphs above 64 nodes take the path of graphs above 512 -- the node sets of the parenting >= 2 walks of step()
     live in prune_scratch instead of registers (longest_path.py:134-143, tsp.py:181-194)."""
     import oracle
-    lib = build_emu.load(extra=["-DGE_MAXW=1"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_maxw1.so"))
-    B, K = 3, 45
+    lib = stress
+    B, K = 2, 30
     env = ge.VectorGraphEnv(env_id, B, device="cpu", _library=lib, obs_mode="flat", autoreset=False, **kw)
     assert env.t["prune_scratch"] is not None
     env.reset(seed=4)
@@ -189,10 +199,10 @@ def test_emulated_residual_walks_in_memory(env_id, kw):
     env.close()
 
 
-def test_emulated_perishable_delivery_placement_of_large_graphs():
+def test_emulated_perishable_delivery_placement_of_large_graphs(stress):
     """-DGE_PPD_WIDE_ABOVE=6: graphs above 6 nodes take the placement of graphs above 128 -- no Floyd-Warshall matrix in LDS,
     distances per pickup, node sets of W words (ge_ppd_place_wide); the fixtures at n = 200 / 300 run on the GPU."""
-    lib = build_emu.load(extra=["-DGE_PPD_WIDE_ABOVE=6"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_ppdwide.so"))
+    lib = stress
     for name in ["ppd_n8_m9_p3", "ppd_n7_m21_complete"]:  # (sparse: placement retries; complete: the closed-form candidate order)
         gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
