@@ -11,27 +11,29 @@
 #include "ge_reset.h"
 
 struct GeFctx {
-  uint64_t *abits; int *rowptr; uint16_t *colw; uint16_t *scw; int *dist;
-  double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's slice)
-  double *bcw0;                                 // slice of wave 0 (the per-wave partial sums are combined in wave order)
-  double *bc, *prx, *prn, *sinv, *diff, *clos;  // shared
+  uint64_t *abits; int *rowptr; uint16_t *colw; uint16_t *scw;
+  uint64_t *sets;                               // per wave: visited set / level being discovered (W words each)
+  double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's area)
+  double *bcw0; int wave_f64;                   // bcw of wave 0 and the float64 stride between waves (partial sums are combined in wave order)
+  double *bc, *clos;                            // common
+  double *prx, *prn, *sinv, *diff, *clus;       // node role
   uint16_t *ord, *lvl;                          // per wave: BFS order of the current source; lvl[d] = where level d starts in it
 };
 
 GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   unsigned char *s = ge_dyn_smem();
   const GeLdsF &L = P.ldsf;
+  const int n = P.n, an = ((n * 8 + 15) & ~15) / 8;
   GeFctx c;
-  c.abits = (uint64_t *)(s + L.abits); c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
-  c.scw = (uint16_t *)(s + L.scw);
-  const int wv = tid >> 6;
-  c.dist = (int *)(s + L.dist + wv * ((P.n * 4 + 15) & ~15));  // (16-byte aligned: the Brandes pass keeps its 64-bit node sets here)
-  double *f = (double *)(s + L.f64a);
-  c.bc = f; c.prx = f + P.n; c.prn = f + 2 * P.n; c.sinv = f + 3 * P.n; c.diff = f + 4 * P.n; c.clos = f + 5 * P.n;
-  double *wsc = f + 6 * P.n;  // [waves][4][n]
-  c.bcw0 = wsc + 3 * P.n;
-  c.sigma = wsc + (wv * 4) * P.n; c.delta = c.sigma + P.n; c.coeff = c.sigma + 2 * P.n; c.bcw = c.sigma + 3 * P.n;
-  c.ord = (uint16_t *)(s + L.ord + wv * L.ord_stride); c.lvl = c.ord + ((2 * P.n + 15) & ~15) / 2;
+  c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
+  c.bc = (double *)(s + L.bc); c.clos = (double *)(s + L.clos);
+  unsigned char *w = s + L.wave0 + (tid >> 6) * L.wave_stride;
+  c.sets = (uint64_t *)w;
+  c.sigma = (double *)(w + L.w_sigma); c.delta = c.sigma + n; c.coeff = c.sigma + 2 * n; c.bcw = c.sigma + 3 * n;
+  c.ord = (uint16_t *)(w + L.w_ord); c.lvl = (uint16_t *)(w + L.w_lvl);
+  c.bcw0 = (double *)(s + L.wave0 + L.w_sigma) + 3 * n; c.wave_f64 = L.wave_stride / 8;
+  c.abits = (uint64_t *)(s + L.abits); c.scw = (uint16_t *)(s + L.scw);
+  c.prx = (double *)(s + L.prx); c.prn = c.prx + an; c.sinv = c.prx + 2 * an; c.diff = c.prx + 3 * an; c.clus = (double *)(s + L.clus);
   return c;
 }
 
@@ -52,23 +54,30 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   const ge_buffers &G = P.buf;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   GeFctx c = ge_carve_f(P, tid);
+  // Two roles (GeLdsF): the Brandes workgroups (a share of the BFS sources each) and the node-level workgroup (clustering, pagerank,
+  // degrees); with nparts == 1 one workgroup is both.  The node role's arrays -- adjacency bit rows, sorted edge copy, pagerank
+  // vectors -- overlay the Brandes role's per-wave areas when the roles are different workgroups, so a Brandes workgroup holds only
+  // what it uses (n = 256: 7 waves where 5 fitted, n = 512: 7 where 4 did) and reads the bit rows of its search from global memory
+  // (8-32 KB per slot, shared by the slot's nine workgroups: cache hits).
+  const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
+  const bool node_role = node_part || nparts == 1, brandes_role = !node_part;
+  const uint64_t *arows = G.adj_bits + nbase * W;        // the slot's adjacency bit rows in HBM
   // stage the slot's graph in LDS
-  for (int i = tid; i < n * W; i += nthreads) c.abits[i] = G.adj_bits[nbase * W + i];
+  if (node_role) for (int i = tid; i < n * W; i += nthreads) c.abits[i] = arows[i];
   for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
   for (int idx = tid; idx < E; idx += nthreads) c.colw[idx] = G.colw[ebase + idx];
   ge_sync();
   // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row (complete graphs: scw IS colw)
-  if (!P.complete) for (int v = tid; v < n; v += nthreads)
+  if (node_role && !P.complete) for (int v = tid; v < n; v += nthreads)
     for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
       uint16_t e = c.colw[k];
       c.scw[c.rowptr[v] + ge_rank_below(c.abits + v * W, e >> 4)] = e;
     }
-  for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
+  if (brandes_role) for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
   ge_sync();
   // Brandes betweenness + closeness: one level-synchronous BFS per source, sources dealt round-robin to the waves
   // complete graph on all n nodes (TSP config 3): every pair is adjacent, so no shortest path has an interior node
   // (betweenness is a sum of zeros) and every BFS has one level of n-1 nodes (closeness (n-1)/(n-1) * (n-1)/(n-1))
-  const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
   const bool trivial = (P.complete && P.ng == n) || node_part;
   if (trivial && !node_part) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
   // One BFS per source, level by level, the nodes kept in discovery order (ord) with the start of every level (lvl): each pass
@@ -82,7 +91,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   //    outside level lev, so the test "is w one level deeper" is gone -- a term sigma(v) * 0.0 = +0.0 leaves the sum as it is, and
   //    every float64 sum keeps the order (and the value) it always had.
   const uint64_t below = (1ull << lane) - 1ull;
-  uint64_t *vis = (uint64_t *)c.dist, *nxt = vis + W;  // visited set / level being discovered (this wave's words)
+  uint64_t *vis = c.sets, *nxt = vis + W;  // visited set / level being discovered (this wave's words)
   int Wp = 1; while (Wp < W) Wp <<= 1;                  // lanes per group: lane = group * Wp + word
   const int NG = GE_WAVE / Wp, gw = lane & (Wp - 1), gg = lane / Wp;
   for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
@@ -93,7 +102,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
     int d = 0, reach = 1, lo = 0, hi = 1; int64_t tot = 0;
     for (;;) {
       uint64_t un = 0;
-      for (int k = lo + gg; k < hi; k += NG) { const int u = c.ord[k]; if (gw < W) un |= c.abits[u * W + gw]; }
+      for (int k = lo + gg; k < hi; k += NG) { const int u = c.ord[k]; if (gw < W) un |= arows[u * W + gw]; }
       for (int off = Wp; off < GE_WAVE; off <<= 1) un |= ge_shfl_u64(un, lane ^ off);
       if (lane < W) { const uint64_t nw = un & ~vis[lane]; vis[lane] |= nw; nxt[lane] = nw; }
       ge_wave_sync();
@@ -161,7 +170,7 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   }
   ge_sync();
   // betweenness: per-wave partial sums (each in source order) added in wave order
-  for (int v = tid; v < n; v += nthreads) { double acc = 0.0; for (int w = 0; w < nwaves; w++) acc += c.bcw0[(w * 4) * n + v]; c.bc[v] = acc; }
+  if (brandes_role) for (int v = tid; v < n; v += nthreads) { double acc = 0.0; for (int w = 0; w < nwaves; w++) acc += c.bcw0[w * c.wave_f64 + v]; c.bc[v] = acc; }
   ge_sync();
   if (nparts > 1) {
     // several workgroups share this slot's sources (few slots, many CUs): closeness of the own sources is final, the
@@ -175,9 +184,9 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   }
   // node-level work, rows dealt to every thread of the workgroup (each node's sums keep their order; the iteration count and
   // the pairwise error sum are the same in every wave)
-  if (n > 2) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = tid; v < n; v += nthreads) c.bc[v] *= scale; }
-  // clustering (directed formula on the symmetric graph) -> wave 0's coeff slice (the Brandes scratch is free now)
-  double *clus = c.bcw0 - n;
+  if (n > 2 && nparts == 1) { double scale = 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2)); for (int v = tid; v < n; v += nthreads) c.bc[v] *= scale; }  // (several parts: ge_k_feat_combine rescales)
+  // clustering (directed formula on the symmetric graph)
+  double *clus = c.clus;
   for (int i = tid; i < n; i += nthreads) {
     int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
     for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) { int j = c.colw[k] >> 4; for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]); }

@@ -45,10 +45,17 @@ struct GeLds {
 };
 
 // LDS carve of the generic structural-feature kernel
+// Two roles share one allocation.  Every workgroup stages rowptr / colw and owns bc / clos.  A Brandes workgroup (a share of the
+// slot's BFS sources) then uses `waves` per-wave areas {two node sets, sigma, delta, coeff, bcw (float64[n] each), order list, level
+// starts}; the node-level workgroup (clustering, pagerank) uses the adjacency bit rows, the sorted edge copy and its float64 arrays
+// INSTEAD -- in the same bytes (`node` == `wave0`) when the two roles are different workgroups (feat_parts > 1), behind the per-wave
+// areas when one workgroup does both.
 struct GeLdsF {
-  int abits, rowptr, colw, scw, dist, f64a, pre, total;
-  int waves;  // waves per workgroup of the generic feature kernel (1..8, as many as LDS allows)
-  int ord, ord_stride;  // per wave: u16[n] BFS order of the current source, then u16[n + 2] where each level starts in it
+  int rowptr, colw, bc, clos;          // common
+  int wave0, wave_stride, waves;       // per-wave areas of the Brandes role
+  int w_sigma, w_ord, w_lvl;           // offsets inside a per-wave area (the node sets are at 0; delta, coeff, bcw follow sigma)
+  int node, abits, scw, prx, clus;     // node role: abits, scw, then prx, prn, sinv, diff (float64[n] each), clus
+  int pre, total;
 };
 
 struct GeParams {
@@ -140,37 +147,49 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
   L.total = o;
 }
 
-// force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry for every class)
-// budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU; the multi-class engine runs
-// its large classes one workgroup per CU)
+// force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry per bucket)
+// budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU)
 static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, int budget = 160 * 1024 / 2) {
   GeLdsF &L = P.ldsf;
   int o = 0;
   auto take = [&](int bytes) { int r = o; o = ge_align16(o + bytes); return r; };
-  L.abits = take(P.n * P.W * 8);
-  L.rowptr = take((P.n + 1) * 4);
-  L.colw = take((P.E > 0 ? P.E : 1) * 2);
-  L.scw = P.complete ? L.colw : take((P.E > 0 ? P.E : 1) * 2);  // [nx] complete_graph: the rows are already in ascending order
+  const int n = P.n, E = P.E > 0 ? P.E : 1;
+  const bool split = P.feat_parts > 1;  // the Brandes role and the node role are different workgroups
+  L.rowptr = take((n + 1) * 4);
+  L.colw = take(E * 2);
+  L.bc = take(n * 8);
+  L.clos = take(n * 8);
+  const int common = o;
+  // per-wave area
+  L.w_sigma = ge_align16(2 * P.W * 8);
+  L.w_ord = L.w_sigma + 4 * n * 8;
+  L.w_lvl = L.w_ord + ge_align16(2 * n);
+  L.wave_stride = ge_align16(L.w_lvl + 2 * (n + 2));
+  // node role
+  const int node_bytes = ge_align16(n * P.W * 8) + (P.complete ? 0 : ge_align16(E * 2)) + 5 * ge_align16(n * 8);
   // the wave count fixes the order of the float64 betweenness partial sums: it is decided from the graph geometry alone (with a
   // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
-  const int shared = o + 1024 + ge_align16(6 * P.n * 8) + 64, per_wave = ge_align16(P.n * 4) + 4 * P.n * 8;
-  L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
-  int waves = (budget - shared) / (per_wave > 0 ? per_wave : 1);
+  const int fixed = common + 1024 + (split ? 0 : node_bytes);
+  int waves = (budget - fixed) / L.wave_stride;
   // a graph so large that half a CU's LDS holds fewer than four waves runs one workgroup per CU with as many as fit all of it
-  // (n = 512: one wave per CU became four)
-  if (waves < 4 && budget < 160 * 1024 - 2048) waves = (160 * 1024 - 2048 - shared) / (per_wave + ge_align16(2 * P.n) + ge_align16(2 * (P.n + 2)) + 16);  // (with the order lists)
+  if (waves < 4 && budget < 160 * 1024 - 2048) waves = (160 * 1024 - 2048 - fixed) / L.wave_stride;
   if (waves > 8) waves = 8;
   if (waves < 1) waves = 1;
-  if (P.n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here
+  if (n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here
   // complete graph on all nodes (TSP config 3): Brandes is skipped, the workgroup is the pagerank over n rows of n-1 entries --
-  // as many waves as fit one workgroup per CU
-  if (P.complete && P.ng == P.n && P.n > 64) { waves = (P.n + 63) / 64; if (waves > 8) waves = 8; }  // one thread per pagerank row: more waves would only hold LDS
+  // one thread per pagerank row: more waves would only hold LDS
+  if (P.complete && P.ng == n && n > 64) { waves = (n + 63) / 64; if (waves > 8) waves = 8; }
   if (force_waves > 0) waves = force_waves;
   L.waves = waves;
-  L.dist = take(waves * ge_align16(P.n * 4));
-  L.f64a = take((6 + 4 * waves) * P.n * 8);
-  // (allocated behind everything the wave count was sized for: the count -- hence the float64 summation order -- is that of round 2)
-  L.ord_stride = ge_align16(2 * P.n) + ge_align16(2 * (P.n + 2));
-  L.ord = take(waves * L.ord_stride);
+  L.wave0 = o;
+  const int waves_end = o + waves * L.wave_stride;
+  L.node = split ? L.wave0 : waves_end;
+  o = L.node;
+  L.abits = take(n * P.W * 8);
+  L.scw = P.complete ? L.colw : take(E * 2);  // [nx] complete_graph: the rows are already in ascending order
+  L.prx = take(4 * ge_align16(n * 8));          // prx, prn, sinv, diff
+  L.clus = take(n * 8);
+  if (o < waves_end) o = waves_end;
+  L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
   L.total = o;
 }
