@@ -458,6 +458,7 @@ extern "C" int ge_attach_spares(ge_engine *e, const ge_spares *sp, void *class_t
   const GeParams &P = e->P;
   const int64_t slot_bytes = (int64_t)P.n * P.F * 4 + (int64_t)P.E * (16 + 4 * P.Fe + 2 + 1 + (P.buf.rev_edge ? 4 : 0)) + (int64_t)P.n * P.W * 8 * (P.buf.range_bits ? 2 : 1) + P.A;
   int parts = (int)(slot_bytes / 8192); if (parts < 1) parts = 1; if (parts > 16) parts = 16;
+  if (parts >= 4) parts = GE_SWAP_GROUPS;  // a large image: one workgroup per (group of) whole arrays
   e->swap_parts = parts;
   e->spares = true;
   // (the caller zeroes `state`; ge_reset / ge_inject_state clear it and refill every image)

@@ -12,6 +12,7 @@
 #include "ge_reset.h"
 #include "ge_step.h"
 
+#define GE_SWAP_GROUPS 10
 // part `p` of `parts` of a byte range, copied by the whole workgroup in the widest unit the three alignments allow
 GE_DEV void ge_copy_part(void *dst, const void *src, int64_t bytes, int p, int parts, int tid, int nt) {
   if (!dst || !src || bytes <= 0) return;
@@ -19,7 +20,12 @@ GE_DEV void ge_copy_part(void *dst, const void *src, int64_t bytes, int p, int p
   if ((al & 15) == 0) {
     const int64_t u = bytes >> 4, lo = u * p / parts, hi = u * (p + 1) / parts;
     const ulonglong2 *s = (const ulonglong2 *)src; ulonglong2 *d = (ulonglong2 *)dst;
-    for (int64_t k = lo + tid; k < hi; k += nt) d[k] = s[k];
+    int64_t k = lo + tid;
+    for (; k + 3 * (int64_t)nt < hi; k += 4 * (int64_t)nt) {  // four loads in flight before the first store
+      const ulonglong2 a = s[k], b = s[k + nt], c = s[k + 2 * (int64_t)nt], e = s[k + 3 * (int64_t)nt];
+      d[k] = a; d[k + nt] = b; d[k + 2 * (int64_t)nt] = c; d[k + 3 * (int64_t)nt] = e;
+    }
+    for (; k < hi; k += nt) d[k] = s[k];
   } else if ((al & 3) == 0) {
     const int64_t u = bytes >> 2, lo = u * p / parts, hi = u * (p + 1) / parts;
     const uint32_t *s = (const uint32_t *)src; uint32_t *d = (uint32_t *)dst;
@@ -37,28 +43,32 @@ GE_DEV void ge_swap_slot(const GeParams &C, const ge_buffers &S, int env, int p,
   const ge_buffers &G = C.buf;
   const int n = C.n, W = C.W, E = C.E;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E, Ne = C.edge_row_stride;
-#define GE_CP(field, off, count) ge_copy_part(G.field ? (void *)(G.field + (off)) : nullptr, S.field ? (const void *)(S.field + (off)) : nullptr, (int64_t)(count) * (int64_t)sizeof(*G.field), p, parts, tid, nt)
-  GE_CP(x, nbase * C.F, (int64_t)n * C.F);
-  GE_CP(edge_index, ebase, E);
-  GE_CP(edge_index, Ne + ebase, E);
-  GE_CP(edge_attr, ebase * C.Fe, (int64_t)E * C.Fe);
-  GE_CP(row_ptr, (int64_t)env * (n + 1), n + 1);
-  GE_CP(colw, ebase, E);
-  GE_CP(scode, ebase, E);
-  GE_CP(sw64, ebase, E);
-  GE_CP(adj_bits, nbase * W, (int64_t)n * W);
-  GE_CP(node_rec, nbase * 2, (int64_t)n * 2);
-  GE_CP(rev_edge, ebase, E);
-  GE_CP(terminals, (int64_t)env * C.T, C.T);
-  GE_CP(node_bits, (int64_t)env * W, W);
-  GE_CP(target_bits, (int64_t)env * W, W);
-  GE_CP(counters, (int64_t)env * 2, 2);
-  GE_CP(mask, (int64_t)env * C.A, C.A);
-  GE_CP(mask_bits, (int64_t)env * C.AW, C.AW);
-  GE_CP(aux_bits, (int64_t)env, 1);
-  GE_CP(node_aux, nbase, n);
-  GE_CP(range_bits, nbase * W, (int64_t)n * W);
-  GE_CP(cover_bits, (int64_t)env * W, W);
+  // parts == GE_SWAP_GROUPS: every part copies WHOLE arrays (the large ones alone: a contiguous 16-byte stream with four loads in
+  // flight); any other count: every part copies its share of every array
+#define GE_CP(group, field, off, count) do { if (parts != GE_SWAP_GROUPS) ge_copy_part(G.field ? (void *)(G.field + (off)) : nullptr, S.field ? (const void *)(S.field + (off)) : nullptr, (int64_t)(count) * (int64_t)sizeof(*G.field), p, parts, tid, nt); \
+    else if (p == (group)) ge_copy_part(G.field ? (void *)(G.field + (off)) : nullptr, S.field ? (const void *)(S.field + (off)) : nullptr, (int64_t)(count) * (int64_t)sizeof(*G.field), 0, 1, tid, nt); } while (0)
+  // (a workgroup's copies are a chain of load -> store round trips to HBM: the small arrays are dealt over several groups)
+  GE_CP(0, edge_index, ebase, E);
+  GE_CP(1, edge_index, Ne + ebase, E);
+  GE_CP(2, edge_attr, ebase * C.Fe, (int64_t)E * C.Fe);
+  GE_CP(3, x, nbase * C.F, (int64_t)n * C.F);
+  GE_CP(4, adj_bits, nbase * W, (int64_t)n * W);
+  GE_CP(4, node_rec, nbase * 2, (int64_t)n * 2);
+  GE_CP(5, rev_edge, ebase, E);
+  GE_CP(5, sw64, ebase, E);
+  GE_CP(6, range_bits, nbase * W, (int64_t)n * W);
+  GE_CP(6, colw, ebase, E);
+  GE_CP(7, scode, ebase, E);
+  GE_CP(7, mask, (int64_t)env * C.A, C.A);
+  GE_CP(7, row_ptr, (int64_t)env * (n + 1), n + 1);
+  GE_CP(8, node_aux, nbase, n);
+  GE_CP(8, terminals, (int64_t)env * C.T, C.T);
+  GE_CP(8, node_bits, (int64_t)env * W, W);
+  GE_CP(8, target_bits, (int64_t)env * W, W);
+  GE_CP(9, counters, (int64_t)env * 2, 2);
+  GE_CP(9, mask_bits, (int64_t)env * C.AW, C.AW);
+  GE_CP(9, aux_bits, (int64_t)env, 1);
+  GE_CP(9, cover_bits, (int64_t)env * W, W);
 #undef GE_CP
   if (p == 0 && tid == 0) {
     // what ge_reset_env's last lines do for a slot regenerated in place: the image carries cost 0, head, destination and (a failed
