@@ -151,8 +151,9 @@ def bind(lib):
     lib.ge_ragged_table_bytes.argtypes = [i32]
     lib.ge_create_ragged.restype = C.c_int
     lib.ge_create_ragged.argtypes = [C.POINTER(GeConfig), C.POINTER(GeBuffers), i32, vp, vp, vp, C.POINTER(vp)]
-    lib.ge_attach_spares.restype = C.c_int
-    lib.ge_attach_spares.argtypes = [vp, C.POINTER(GeSpares), vp]
+    if hasattr(lib, "ge_attach_spares"):  # (tools/old_vs_new_step.py binds a library of ABI 3 for a timing comparison)
+        lib.ge_attach_spares.restype = C.c_int
+        lib.ge_attach_spares.argtypes = [vp, C.POINTER(GeSpares), vp]
     lib.ge_reset.restype = C.c_int
     lib.ge_reset.argtypes = [vp, vp, vp]
     for name in ("ge_step", "ge_step_only"):
