@@ -510,7 +510,16 @@ GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32
   // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
   double bc = 0.0;
   if (live && !(GE_F64_ABL & 16)) {
-    for (int src = 0; src < n; src++) if (src != lane) bc += (double)c.sig[lane * GE_F64_SS + src] * c.del[lane * GE_F64_SD + src];  // delta = sigma * S
+    // delta = sigma * S, added in source order.  Eight sources per trip with their sixteen LDS reads in flight (the additions stay a
+    // chain, in order); the node's own column and the columns of sources that do not exist (zero, never written) add +0.0.
+#pragma unroll 1
+    for (int s0 = 0; s0 < 64; s0 += 8) {
+      uint32_t sg[8]; double sv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { sg[k] = c.sig[lane * GE_F64_SS + s0 + k]; sv[k] = c.del[lane * GE_F64_SD + s0 + k]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) bc += (s0 + k != lane) ? (double)sg[k] * sv[k] : 0.0;
+    }
     if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
   }
   const double clos = live ? c.clos[lane] : 0.0;

@@ -393,9 +393,10 @@ def test_randomized_configs_match_oracle(chunk):
     with the CPU oracle (which is pinned by the reference fixtures)"""
     import oracle
     ge = _ge()
-    rng = np.random.default_rng(20260 + chunk)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("GE_FUZZ_SEED", 20260)) + chunk)  # (GE_FUZZ_SEED / GE_FUZZ_CONFIGS: a longer soak with other seeds)
     done_cfgs = 0
-    for _ in range(12):
+    for _ in range(int(os.environ.get("GE_FUZZ_CONFIGS", 12))):
         env_id, kw = _random_config(rng)
         B, K, stride, base, s0 = 6, 30, 101, 5, int(rng.integers(0, 2**32))
         try:
