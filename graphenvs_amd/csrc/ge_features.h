@@ -29,9 +29,11 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   c.bc = (double *)(s + L.bc); c.clos = (double *)(s + L.clos);
   unsigned char *w = s + L.wave0 + (tid >> 6) * L.wave_stride;
   c.sets = (uint64_t *)w;
-  c.sigma = (double *)(w + L.w_sigma); c.delta = c.sigma + n; c.coeff = c.sigma + 2 * n; c.bcw = c.sigma + 3 * n;
+  // (P.W <= GE_BCW_REG_W: the wave's betweenness partial sums live in registers while it runs and are handed over in delta[])
+  const int bcw_at = P.W <= GE_BCW_REG_W ? n : 3 * n;
+  c.sigma = (double *)(w + L.w_sigma); c.delta = c.sigma + n; c.coeff = c.sigma + 2 * n; c.bcw = c.sigma + bcw_at;
   c.ord = (uint16_t *)(w + L.w_ord); c.lvl = (uint16_t *)(w + L.w_lvl);
-  c.bcw0 = (double *)(s + L.wave0 + L.w_sigma) + 3 * n; c.wave_f64 = L.wave_stride / 8;
+  c.bcw0 = (double *)(s + L.wave0 + L.w_sigma) + bcw_at; c.wave_f64 = L.wave_stride / 8;
   c.abits = (uint64_t *)(s + L.abits); c.scw = (uint16_t *)(s + L.scw);
   c.prx = (double *)(s + L.prx); c.prn = c.prx + an; c.sinv = c.prx + 2 * an; c.diff = c.prx + 3 * an; c.clus = (double *)(s + L.clus);
   return c;
@@ -46,7 +48,59 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
 #define GE_FABL 0  // diagnostic ablation bits of the generic feature kernel (tools/variant_reset.py; the results are wrong by construction): 1 forward
                    // push, 2 backward coefficient pass, 4 backward pull, 8 pagerank iterations; 0 when shipped
 #endif
+// Diagnostic build only (-DGE_STAMPS, never shipped; tools/feat_phase_clocks.py): shader-clock cycles wave 0 of slot 0's first Brandes
+// workgroup spends in the phases of the generic kernel -- [k] = cycles from stamp k to the next stamp, summed over sources and levels:
+// 0 level discovery, 1 path-count pull, 2 front update, 3 coefficients, 4 dependency pull, 5 end of a source, 6 set-up of a source;
+// ge_stamp_buf[16 + k]; [24] = sources, [25] = levels
+#if defined(GE_STAMPS) && !defined(GE_EMU)
+#define GE_FSTAMP_DECL unsigned long long fs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fs_t = clock64(), fs_src = 0, fs_lev = 0; int fs_k = 7
+#define GE_FSTAMP(k) do { const unsigned long long now_ = clock64(); fs_acc[fs_k] += now_ - fs_t; fs_t = now_; fs_k = (k); if ((k) == 6) fs_src++; if ((k) == 1) fs_lev++; } while (0)
+#define GE_FSTAMP_OUT do { if (env == 0 && part == 0 && tid == 0) { for (int k_ = 0; k_ < 8; k_++) ge_stamp_buf[16 + k_] = fs_acc[k_]; ge_stamp_buf[24] = fs_src; ge_stamp_buf[25] = fs_lev; } } while (0)
+#else
+#define GE_FSTAMP_DECL do { } while (0)
+#define GE_FSTAMP(k) do { } while (0)
+#define GE_FSTAMP_OUT do { } while (0)
+#endif
 GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat_parts + 1 : 1; }
+// One pull of the Brandes pass over the nodes ord[k0 .. k1): a lane takes TWO nodes (k, k + 64) and walks both rows together, eight
+// entries of each per trip -- the pass is a chain of LDS round trips (order list -> row bounds -> neighbour ids -> their values), and
+// on one node with four entries per trip a level of 150 nodes cost three such chains one after the other (4 400 cycles per level
+// at n = 256, tools/feat_phase_clocks.py).  DELTA false: sigma[v] = sum of front[u] (path counts: integers, exact in any order).
+// DELTA true: delta[v] = sum of sigma[v] * coeff[w] IN ROW ORDER; an entry past the end of the row adds sigma[v] * 0.0 = +0.0.
+template <bool DELTA>
+GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
+  constexpr int U = 2, CH = 8;
+  for (int kb = k0; kb < k1; kb += U * GE_WAVE) {
+    int v[U], e[U], r1[U]; bool on[U]; double acc[U], sv[U];
+#pragma unroll
+    // every load below is UNCONDITIONAL, from an address that is valid whatever the lane holds (k0, node 0 / row entry 0 stand in),
+    // and the value is selected afterwards: a load under a condition compiles to a branch around it with a wait behind it, one LDS
+    // round trip per entry
+    for (int u = 0; u < U; u++) { const int k = kb + u * GE_WAVE + lane; on[u] = k < k1; v[u] = (int)c.ord[on[u] ? k : k0]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int a = c.rowptr[v[u]], b = c.rowptr[v[u] + 1]; e[u] = on[u] ? a : 0; r1[u] = on[u] ? b : 0; sv[u] = DELTA ? c.sigma[v[u]] : 1.0; acc[u] = 0.0; }
+    while (e[0] < r1[0] || e[1] < r1[1]) {
+      int w[U][CH]; double f[U][CH]; bool ok[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < CH; j++) { ok[u][j] = e[u] + j < r1[u]; w[u][j] = (int)(c.colw[ok[u][j] ? e[u] + j : 0] >> 4); }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < CH; j++) { const double x = c.coeff[w[u][j]]; f[u][j] = ok[u][j] ? x : 0.0; }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) acc[u] += DELTA ? sv[u] * f[u][j] : f[u][j];
+        e[u] += CH;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) if (on[u]) (DELTA ? c.delta : c.sigma)[v[u]] = acc[u];
+  }
+}
+
 GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid_fresh(), nthreads = ge_bdim();
   const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
@@ -73,7 +127,11 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
       uint16_t e = c.colw[k];
       c.scw[c.rowptr[v] + ge_rank_below(c.abits + v * W, e >> 4)] = e;
     }
-  if (brandes_role) for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
+  const bool bcw_reg = W <= GE_BCW_REG_W;  // the wave's betweenness partial sums in registers: node lane + 64 j in bcr[j]
+  double bcr[GE_BCW_REG_W];
+#pragma unroll
+  for (int j = 0; j < GE_BCW_REG_W; j++) bcr[j] = 0.0;
+  if (brandes_role && !bcw_reg) for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
   ge_sync();
   // Brandes betweenness + closeness: one level-synchronous BFS per source, sources dealt round-robin to the waves
   // complete graph on all n nodes (TSP config 3): every pair is adjacent, so no shortest path has an interior node
@@ -94,15 +152,25 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
   uint64_t *vis = c.sets, *nxt = vis + W;  // visited set / level being discovered (this wave's words)
   int Wp = 1; while (Wp < W) Wp <<= 1;                  // lanes per group: lane = group * Wp + word
   const int NG = GE_WAVE / Wp, gw = lane & (Wp - 1), gg = lane / Wp;
+  GE_FSTAMP_DECL;
   for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
+    GE_FSTAMP(6);
     for (int v = lane; v < n; v += GE_WAVE) { c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; c.coeff[v] = (v == s) ? 1.0 : 0.0; }
     if (lane < W) vis[lane] = ((s >> 6) == lane) ? (1ull << (s & 63)) : 0ull;
     if (lane == 0) { c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; }
     ge_wave_sync();
     int d = 0, reach = 1, lo = 0, hi = 1; int64_t tot = 0;
     for (;;) {
+      GE_FSTAMP(0);
       uint64_t un = 0;
-      for (int k = lo + gg; k < hi; k += NG) { const int u = c.ord[k]; if (gw < W) un |= arows[u * W + gw]; }
+      for (int k = lo + gg; k < hi; k += 8 * NG) {  // eight rows per trip: the (global) loads of a trip are in flight together
+        int u[8]; uint64_t r[8]; bool ok[8];  // (unconditional loads from addresses that are always valid, selected afterwards: see ge_brandes_pull)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { ok[j] = k + j * NG < hi && gw < W; u[j] = (int)c.ord[ok[j] ? k + j * NG : lo]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const uint64_t x = arows[u[j] * W + (gw < W ? gw : 0)]; r[j] = ok[j] ? x : 0ull; }
+        un |= ((r[0] | r[1]) | (r[2] | r[3])) | ((r[4] | r[5]) | (r[6] | r[7]));
+      }
       for (int off = Wp; off < GE_WAVE; off <<= 1) un |= ge_shfl_u64(un, lane ^ off);
       if (lane < W) { const uint64_t nw = un & ~vis[lane]; vis[lane] |= nw; nxt[lane] = nw; }
       ge_wave_sync();
@@ -114,59 +182,47 @@ GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int 
       }
       if (!found) break;
       ge_wave_sync();
-      for (int k = hi + lane; k < hi + found && !(GE_FABL & 1); k += GE_WAVE) {
-        const int v = c.ord[k];
-        double acc = 0.0;
-        const int r1 = c.rowptr[v + 1];
-        for (int e = c.rowptr[v]; e < r1; e += 4) {  // four edges per trip: the LDS round trips of the four overlap
-          int u[4]; double f[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) u[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
-#pragma unroll
-          for (int j = 0; j < 4; j++) f[j] = (u[j] >= 0) ? c.coeff[u[j]] : 0.0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc += f[j];
-        }
-        c.sigma[v] = acc;
-      }
+      GE_FSTAMP(1);
+      if (!(GE_FABL & 1)) ge_brandes_pull<false>(c, hi, hi + found, lane);
       ge_wave_sync();
+      GE_FSTAMP(2);
       for (int k = lo + lane; k < hi; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;                                     // the front moves on
       for (int k = hi + lane; k < hi + found; k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = c.sigma[v]; }
       d++; lo = hi; hi += found; reach += found; tot += (int64_t)d * found;
       if (lane == 0) c.lvl[d + 1] = (uint16_t)hi;
       ge_wave_sync();
     }
+    GE_FSTAMP(0);
     for (int k = lo + lane; k < hi; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;  // coeff[] is all zero again
     ge_wave_sync();
     for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
+      GE_FSTAMP(3);
       const int l0 = c.lvl[lev], l1 = c.lvl[lev + 1], p0 = c.lvl[lev - 1];
-      for (int k = l0 + lane; k < l1 && !(GE_FABL & 2); k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; c.bcw[v] += c.delta[v]; }
+      for (int k = l0 + lane; k < l1 && !(GE_FABL & 2); k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; if (!bcw_reg) c.bcw[v] += c.delta[v]; }
       ge_wave_sync();
-      for (int k = p0 + lane; k < l0 && !(GE_FABL & 4); k += GE_WAVE) {
-        const int v = c.ord[k];
-        double acc = 0.0; const double sv = c.sigma[v];
-        const int r1 = c.rowptr[v + 1];
-        for (int e = c.rowptr[v]; e < r1; e += 4) {  // four edges per trip; the sum keeps its row order
-          int w[4]; double cf[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) w[j] = (e + j < r1) ? (int)(c.colw[e + j] >> 4) : -1;
-#pragma unroll
-          for (int j = 0; j < 4; j++) cf[j] = (w[j] >= 0) ? c.coeff[w[j]] : 0.0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc += sv * cf[j];  // (+0.0 for a neighbour that is not one level deeper)
-        }
-        c.delta[v] = acc;
-      }
+      GE_FSTAMP(4);
+      if (!(GE_FABL & 4)) ge_brandes_pull<true>(c, p0, l0, lane);  // (+0.0 for a neighbour that is not one level deeper)
       ge_wave_sync();
       for (int k = l0 + lane; k < l1; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;
     }
+    GE_FSTAMP(5);
     ge_wave_sync();
+    if (bcw_reg) {  // betweenness[v] += delta_s(v), v != s, in source order (a node the search did not reach, or of the last level, adds +0.0)
+#pragma unroll
+      for (int j = 0; j < GE_BCW_REG_W; j++) { const int v = lane + GE_WAVE * j; if (j < W) bcr[j] += (v < n && v != s) ? c.delta[v] : 0.0; }
+    }
     if (lane == 0) {  // closeness_centrality, wf_improved
       double cc = 0.0;
       if (tot > 0 && n > 1) { cc = ((double)reach - 1.0) / (double)tot; double sc = ((double)reach - 1.0) / (double)(n - 1); cc *= sc; }
       c.clos[s] = cc;
     }
     ge_wave_sync();
+  }
+  GE_FSTAMP(7);
+  GE_FSTAMP_OUT;
+  if (bcw_reg && brandes_role) {  // (this wave's delta[] is free now: every one of its searches is over)
+#pragma unroll
+    for (int j = 0; j < GE_BCW_REG_W; j++) { const int v = lane + GE_WAVE * j; if (j < W && v < n) c.bcw[v] = bcr[j]; }
   }
   ge_sync();
   // betweenness: per-wave partial sums (each in source order) added in wave order

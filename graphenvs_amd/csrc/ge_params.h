@@ -149,6 +149,7 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
 
 // force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry per bucket)
 // budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU)
+#define GE_BCW_REG_W 8  // graphs of up to 512 nodes: a wave of the generic feature kernel keeps its betweenness partial sums in registers
 static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, int budget = 160 * 1024 / 2) {
   GeLdsF &L = P.ldsf;
   int o = 0;
@@ -162,7 +163,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   const int common = o;
   // per-wave area
   L.w_sigma = ge_align16(2 * P.W * 8);
-  L.w_ord = L.w_sigma + 4 * n * 8;
+  L.w_ord = L.w_sigma + (P.W <= GE_BCW_REG_W ? 3 : 4) * n * 8;  // sigma, delta, coeff (+ bcw when the partial sums do not fit registers)
   L.w_lvl = L.w_ord + ge_align16(2 * n);
   L.wave_stride = ge_align16(L.w_lvl + 2 * (n + 2));
   // node role

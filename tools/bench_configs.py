@@ -16,14 +16,15 @@ CONFIGS = {
     "dc": ("DistributionCenter-v0", dict(n_nodes=64, n_edges=192), 65536, 100),
     "ppd": ("PerishableProductDelivery-v0", dict(n_nodes=64, n_edges=192, parenting=1), 16384, 300),
 }
-def bench_c5(slots_per_id=16384, n_sizes=481, K=100):
+def bench_c5(slots_per_id=16384, n_sizes=481, K=100, ids=(0, 1, 2)):
     """BASELINE config 5: mixed {ShortestPath, MaxIndependentSet, DensestSubgraph}, n ~ U{32..512} (every size), m = 3n; one
     multi-class engine (one launch sequence) per env id"""
     import numpy as np
     rng = np.random.default_rng(0)
     members = []
-    for eid, extra in (("ShortestPath-v0", {}), ("MaxIndependentSet-v0", {}), ("DensestSubgraph-v0", dict(parenting=1))):
+    for k, (eid, extra) in enumerate((("ShortestPath-v0", {}), ("MaxIndependentSet-v0", {}), ("DensestSubgraph-v0", dict(parenting=1)))):
         ns = rng.integers(32, 513, slots_per_id)
+        if k not in ids: continue  # (c5sp / c5mis / c5ds: one member alone, same size draw)
         sizes = [(int((ns == n).sum()), int(n), 3 * int(n)) for n in np.unique(ns)]
         members.append(ge.RaggedVectorEnv(eid, sizes, **extra))
     mixed = ge.MixedVectorEnv(members)
@@ -39,8 +40,8 @@ def bench_c5(slots_per_id=16384, n_sizes=481, K=100):
 
 
 for name in (sys.argv[1:] or ["c3", "c4"]):
-    if name == "c5":
-        bench_c5()
+    if name in ("c5", "c5sp", "c5mis", "c5ds"):
+        bench_c5(ids={"c5": (0, 1, 2), "c5sp": (0,), "c5mis": (1,), "c5ds": (2,)}[name])
         continue
     name, _, pf = name.partition("@")  # name@period: with episode prefetch (spares), refill every `period` steps
     env_id, kw, B, K = CONFIGS[name]
