@@ -101,7 +101,7 @@ GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
   }
 }
 
-GE_DEVFN void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
+GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid_fresh(), nthreads = ge_bdim();
   const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
   const int n = P.n, W = P.W, E = P.E, F = P.F, t = P.env_type;
@@ -359,7 +359,7 @@ typedef uint64_t ge_slice_t;  // one lane per source: the lane serves every targ
 typedef uint32_t ge_slice_t;
 #define GE_SLICE_CTZ(x) ((int)__builtin_ctz(x))
 #endif
-GE_DEVFN void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32_t *work_count, int32_t *work_list, int env_global) {
+GE_DEV void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32_t *work_count, int32_t *work_list, int env_global) {
   const int tid = ge_tid_fresh();
   const bool node_wave = tid >= GE_F64_WALKERS;
   const int lane = tid - GE_F64_WALKERS;  // node index inside the node wave

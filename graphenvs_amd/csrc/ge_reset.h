@@ -56,6 +56,42 @@ GE_DEV void ge_mt_twist(uint32_t *mt, int lane) {
   }
 }
 
+// The same regeneration with the state in REGISTERS: word 64 r + lane in R[r] (row 9: lanes 0-47).  The long draws (an n x n delay
+// matrix is 1.14 n^2 raw words: 480 blocks at n = 512) spent most of a block in the six LDS round trips of ge_mt_twist and the reads
+// of the scan behind it; here a block is ~12 register operations per row and the neighbours come through the lane crossbar
+// (ds_bpermute: no LDS memory, no ordering points).  Rows are regenerated in order, so a row reads the rows behind it already NEW
+// and the rows ahead still OLD -- exactly the in-place algorithm:
+//   word i+1   : lane + 1 of the row (lane 63: lane 0 of the next row; word 623: the NEW word 0);
+//   word i+397 : for i < 227 the old rows r + 6 / r + 7 rotated by 13 lanes; for i >= 227 the new word i - 227 = rows r - 4 / r - 3
+//                rotated by 29 lanes (row 3 straddles word 227 and takes both).
+// Each source lane picks the row its reader wants, so a row costs two crossbar reads.
+GE_DEV uint32_t ge_mt_mix(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+#define GE_MT_ROWS 10
+GE_DEV void ge_mt_twist_regs(uint32_t (&R)[GE_MT_ROWS], int lane) {
+  const int l1 = (lane + 1) & 63, l13 = (lane + 13) & 63, l29 = (lane + 29) & 63;
+#pragma unroll
+  for (int r = 0; r < GE_MT_ROWS; r++) {
+    uint32_t B, C;
+    if (r < GE_MT_ROWS - 1) B = ge_shfl_u32(lane == 0 ? R[r + 1] : R[r], l1);
+    else B = ge_shfl_u32(lane == 0 ? R[0] : R[r], lane == 47 ? 0 : l1);
+    if (r < 3) C = ge_shfl_u32(lane >= 13 ? R[r + 6] : R[r + 7], l13);
+    else if (r == 3) { const uint32_t c1 = ge_shfl_u32(R[9], l13), c2 = ge_shfl_u32(R[0], l29); C = lane < 35 ? c1 : c2; }
+    else C = ge_shfl_u32(lane >= 29 ? R[r - 4] : R[r - 3], l29);
+    R[r] = ge_mt_mix(R[r], B, C);
+  }
+}
+GE_DEV void ge_mt_to_regs(uint32_t (&R)[GE_MT_ROWS], const uint32_t *mt, int lane) {
+#pragma unroll
+  for (int r = 0; r < GE_MT_ROWS; r++) R[r] = mt[(GE_WAVE * r + lane < GE_MT_N) ? GE_WAVE * r + lane : 0];
+}
+GE_DEV void ge_mt_from_regs(uint32_t *mt, const uint32_t (&R)[GE_MT_ROWS], int lane) {
+#pragma unroll
+  for (int r = 0; r < GE_MT_ROWS; r++) if (GE_WAVE * r + lane < GE_MT_N) mt[GE_WAVE * r + lane] = R[r];
+}
+
 // random.seed(int) for 0 <= s < 2^32: init_by_array([s]) ([py] _randommodule.c).  1 246 dependent steps, run by
 // lane 0 on the vector ALU (measured: the scalar-ALU form of the same chain is 1.6x slower on gfx950).  Collective.
 GE_DEV void ge_mt_seed_python(uint32_t *mt, uint32_t seed, int lane) {
@@ -281,6 +317,25 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
   const uint32_t bm = (sink == 3) ? 3u : 7u;
   const uint64_t below = (1ull << lane) - 1ull;
   while (base < total) {
+    if (nppos >= GE_MT_N && total - base > GE_MT_N) {
+      // whole blocks of 624 raw words that cannot end the sequence (a block accepts at most 624): generated and scanned in registers
+      uint32_t R[GE_MT_ROWS];
+      ge_mt_to_regs(R, mt, lane);
+      do {
+        ge_mt_twist_regs(R, lane);
+#pragma unroll
+        for (int k = 0; k < GE_MT_ROWS; k++) {  // (a row at a time: nothing but the state stays live across the rows)
+          const uint32_t val = (GE_WAVE * k + lane < GE_MT_N) ? (ge_temper(R[k]) & bm) : bm;
+          const uint64_t bal = ge_ballot(val < bm);
+          if (val < bm) ge_np_sink(P, c, sink, base + ge_popc64(bal & below), val);
+          base += ge_popc64(bal);
+        }
+      } while (total - base > GE_MT_N);
+      ge_mt_from_regs(mt, R, lane);
+      ge_wave_sync();
+      nppos = GE_MT_N;  // (the block in LDS is used up)
+      continue;
+    }
     if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
     // four chunks of 64 raw words at a time while they lie inside the current block and cannot finish the sequence: the four
     // state reads, tempering chains and ballots are independent, which is what a single wave needs to stay off the LDS latency
@@ -374,21 +429,33 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
     }
   };
   while (base < total) {
-    if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
-    if (nppos == 0 && total - base > GE_MT_N) {  // a whole block of 624 raw words that cannot end the sequence: ten chunks in one trip
-      uint32_t val[10]; uint64_t bal[10]; int cnt[10];
+    if (nppos >= GE_MT_N && total - base > GE_MT_N) {
+      // whole blocks of 624 raw words that cannot end the sequence (a block accepts at most 624): generated and scanned in registers,
+      // ten chunks per trip
+      uint32_t R[GE_MT_ROWS];
+      ge_mt_to_regs(R, mt, lane);
+      do {
+        ge_mt_twist_regs(R, lane);
+        // count first (ballots and popcounts: scalar registers); the block is looked at again only when a wanted cell lies in it
+        // (about one block in three at n = 512)
+        int tot = 0;
 #pragma unroll
-      for (int k = 0; k < 10; k++) { const int idx = GE_WAVE * k + lane; val[k] = idx < GE_MT_N ? (ge_temper(mt[idx]) & 7u) : 7u; }
-      int tot = 0;
+        for (int k = 0; k < GE_MT_ROWS; k++) tot += ge_popc64(ge_ballot(GE_WAVE * k + lane < GE_MT_N && (ge_temper(R[k]) & 7u) < 7u));
+        if (next - (uint32_t)base < (uint32_t)tot) {
 #pragma unroll
-      for (int k = 0; k < 10; k++) { bal[k] = ge_ballot(val[k] < 7u); cnt[k] = ge_popc64(bal[k]); tot += cnt[k]; }
-      if (next - (uint32_t)base < (uint32_t)tot) {
-#pragma unroll
-        for (int k = 0; k < 10; k++) { take(val[k], bal[k], cnt[k]); base += cnt[k]; }
-      } else base += tot;
-      nppos = GE_MT_N;
+          for (int k = 0; k < GE_MT_ROWS; k++) {
+            const uint32_t val = (GE_WAVE * k + lane < GE_MT_N) ? (ge_temper(R[k]) & 7u) : 7u;
+            const uint64_t bal = ge_ballot(val < 7u); const int cnt = ge_popc64(bal);
+            take(val, bal, cnt); base += cnt;
+          }
+        } else base += tot;
+      } while (total - base > GE_MT_N);
+      ge_mt_from_regs(mt, R, lane);
+      ge_wave_sync();
+      nppos = GE_MT_N;  // (the block in LDS is used up)
       continue;
     }
+    if (nppos >= GE_MT_N) { ge_mt_twist(mt, lane); nppos = 0; }
     if (GE_MT_N - nppos >= 4 * GE_WAVE) {
       uint32_t val[4]; uint64_t bal[4]; int cnt[4];
 #pragma unroll
@@ -1153,7 +1220,7 @@ GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, cons
 }
 
 template <int ENV>
-GE_DEVFN void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, const GeRun &run, const GeInject &inj) {
+GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, const GeRun &run, const GeInject &inj) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
   // Inside a wave only wave-level hand-offs are used; the two block barriers are the join and the end of the slot.
   const int tid = ge_tid_fresh();
