@@ -72,15 +72,30 @@ GE_DEV uint32_t ge_mt_mix(uint32_t a, uint32_t b, uint32_t c) {
 #define GE_MT_ROWS 10
 GE_DEV void ge_mt_twist_regs(uint32_t (&R)[GE_MT_ROWS], int lane) {
   const int l1 = (lane + 1) & 63, l13 = (lane + 13) & 63, l29 = (lane + 29) & 63;
+  // Four batches of rows -- {0, 1, 2} {3, 4, 5} {6, 7, 8} {9} -- whose members do not depend on one another (a row needs the rows
+  // four and three behind it NEW): the crossbar reads of a batch are issued together, one round trip per batch instead of one per row
+  uint32_t B[3], C[3];
 #pragma unroll
-  for (int r = 0; r < GE_MT_ROWS; r++) {
-    uint32_t B, C;
-    if (r < GE_MT_ROWS - 1) B = ge_shfl_u32(lane == 0 ? R[r + 1] : R[r], l1);
-    else B = ge_shfl_u32(lane == 0 ? R[0] : R[r], lane == 47 ? 0 : l1);
-    if (r < 3) C = ge_shfl_u32(lane >= 13 ? R[r + 6] : R[r + 7], l13);
-    else if (r == 3) { const uint32_t c1 = ge_shfl_u32(R[9], l13), c2 = ge_shfl_u32(R[0], l29); C = lane < 35 ? c1 : c2; }
-    else C = ge_shfl_u32(lane >= 29 ? R[r - 4] : R[r - 3], l29);
-    R[r] = ge_mt_mix(R[r], B, C);
+  for (int r = 0; r < 3; r++) { B[r] = ge_shfl_u32(lane == 0 ? R[r + 1] : R[r], l1); C[r] = ge_shfl_u32(lane >= 13 ? R[r + 6] : R[r + 7], l13); }
+#pragma unroll
+  for (int r = 0; r < 3; r++) R[r] = ge_mt_mix(R[r], B[r], C[r]);
+  {
+    const uint32_t c1 = ge_shfl_u32(R[9], l13), c2 = ge_shfl_u32(R[0], l29);
+#pragma unroll
+    for (int r = 3; r < 6; r++) B[r - 3] = ge_shfl_u32(lane == 0 ? R[r + 1] : R[r], l1);
+#pragma unroll
+    for (int r = 4; r < 6; r++) C[r - 3] = ge_shfl_u32(lane >= 29 ? R[r - 4] : R[r - 3], l29);
+    C[0] = lane < 35 ? c1 : c2;
+#pragma unroll
+    for (int r = 3; r < 6; r++) R[r] = ge_mt_mix(R[r], B[r - 3], C[r - 3]);
+  }
+#pragma unroll
+  for (int r = 6; r < 9; r++) { B[r - 6] = ge_shfl_u32(lane == 0 ? R[r + 1] : R[r], l1); C[r - 6] = ge_shfl_u32(lane >= 29 ? R[r - 4] : R[r - 3], l29); }
+#pragma unroll
+  for (int r = 6; r < 9; r++) R[r] = ge_mt_mix(R[r], B[r - 6], C[r - 6]);
+  {
+    const uint32_t b9 = ge_shfl_u32(lane == 0 ? R[0] : R[9], lane == 47 ? 0 : l1), c9 = ge_shfl_u32(lane >= 29 ? R[5] : R[6], l29);
+    R[9] = ge_mt_mix(R[9], b9, c9);
   }
 }
 GE_DEV void ge_mt_to_regs(uint32_t (&R)[GE_MT_ROWS], const uint32_t *mt, int lane) {
@@ -281,15 +296,18 @@ struct GeInject { const int64_t *links; const uint8_t *wcode; const float *x; co
 __device__ unsigned long long ge_stamp_buf[32];
 #define GE_STAMP(k) do { if (lane == 0 && env == 0) { ge_stamp_buf[k] = wall_clock64(); if ((k) == 11) ge_stamp_buf[30] = clock64(); if ((k) == 17) ge_stamp_buf[31] = clock64(); } } while (0)  // 30 / 31: the shader clock (s_memtime) at the ends of the n <= 64 feature kernel's slot 0
 #define GE_STAMP_T0(k) do { if (tid == 0 && env == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)
+#define GE_STAMP_B0(k) do { if (lane == 0 && ge_bid() == 0) ge_stamp_buf[k] = wall_clock64(); } while (0)  // (workgroup 0 = slot 0 of a full reset)
 #elif defined(GE_STAMP_SLOTS) && !defined(GE_EMU)
 // Diagnostic build only (-DGE_STAMP_SLOTS, never shipped; tools/slot_times.py): when every slot's regeneration starts (stamp 0), when
 // its graph is accepted (stamp 2) and when it is written (stamp 10), 100 MHz, into final_cost / final_len / final_heur of the slot --
 // the outputs of the step are garbage in such a build
 #define GE_STAMP(k) do { if (lane == 0) { if ((k) == 0) P.buf.final_cost[env] = (double)wall_clock64(); else if ((k) == 2) P.buf.final_len[env] = (int32_t)(wall_clock64() - (unsigned long long)P.buf.final_cost[env]); else if ((k) == 10) P.buf.final_heur[env] = (double)wall_clock64(); } } while (0)
 #define GE_STAMP_T0(k) do { } while (0)
+#define GE_STAMP_B0(k) do { } while (0)
 #else
 #define GE_STAMP(k) do { } while (0)
 #define GE_STAMP_T0(k) do { } while (0)
+#define GE_STAMP_B0(k) do { } while (0)
 #endif
 
 
@@ -416,6 +434,7 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
   // The hot loop touches no graph structure: the wanted cells are held 64 at a time in a register (lane j: cell number t0 + j, read
   // with v_readlane), and the accepted draw that lands on one is stored by its lane as tcode[t]; the codes go to their two slots
   // of the ascending-neighbour order afterwards, one lane per edge.
+  GE_STAMP_B0(7);
   int base = 0, t = 0, t0 = 0;
   uint32_t treg = lane < m ? tcell[lane] : 0xffffffffu;
   uint32_t next = ge_readlane_u32(treg, 0);
@@ -492,6 +511,7 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
     }
   }
   ge_wave_sync();
+  GE_STAMP_B0(8);
   for (int e = lane; e < m; e += GE_WAVE) {  // delay[u, v] of edge number e, to both directions
     const uint32_t cell = tcell[e];
     const int u = (int)(cell / (uint32_t)n), v = (int)(cell - (uint32_t)u * (uint32_t)n);
