@@ -71,8 +71,11 @@ class RaggedVectorEnv:
                                                      self._class_start.data_ptr(), C.byref(h)), "ge_create_ragged")
         self._h = h
         # episode prefetch (include/graphenvs.h, ge_attach_spares): a ragged batch is where it pays most -- every step a few slots of
-        # many different sizes finish, and regenerated in place they cost the step the latency of the largest of them
-        self.prefetch = (16 if autoreset and _library is None else 0) if prefetch is None else int(prefetch)
+        # many different sizes finish, and regenerated in place they cost the step the latency of the largest of them.  Refill every
+        # 4 steps by default: on BASELINE config 5 (profiles/r03_c5_refill_period.txt) 0 / 2 / 4 / 6 / 8 / 16 / 32 steps give
+        # 15.3 / 19.6 / 20.8 / 19.1 / 19.0 / 17.2 / 16.0 M env-steps/s -- the small classes' episodes last a handful of steps, and a
+        # slot that finishes again before its image is refilled takes the in-place path
+        self.prefetch = (4 if autoreset and _library is None else 0) if prefetch is None else int(prefetch)
         self.spare = None
         if self.prefetch and autoreset:
             self._attach_spares()
@@ -172,26 +175,51 @@ class RaggedVectorEnv:
 
 class MixedVectorEnv:
     """Several env ids side by side (each a RaggedVectorEnv or VectorGraphEnv); step takes one action tensor per
-    member.  Observation widths differ between ids (utils.get_env_info), so each member keeps its own PyG view."""
+    member.  Observation widths differ between ids (utils.get_env_info), so each member keeps its own PyG view.
 
-    def __init__(self, members):
+    The members are independent engines, so on the GPU every call fans out over one HIP stream per member and joins on the caller's
+    stream before it returns (``concurrent=False``: one after the other on the caller's stream): the regeneration kernels of a
+    member with large graphs hold a workgroup per CU for hundreds of microseconds, and the other members' launches fill the rest
+    of the chip meanwhile.  Results do not depend on it -- nothing is shared between members."""
+
+    def __init__(self, members, concurrent=True):
         self.members = list(members)
         self.num_envs = sum(m.num_envs for m in self.members)
+        dev = getattr(self.members[0], "device", None)
+        self._cuda = concurrent and dev is not None and torch.device(dev).type == "cuda" and len(self.members) > 1
+        self._streams = [torch.cuda.Stream(device=dev) for _ in self.members] if self._cuda else None
+
+    def _each(self, fn, args=None):
+        """fn(member[, arg]) for every member: on the member's own stream between a fork from and a join on the current stream"""
+        args = [None] * len(self.members) if args is None else list(args)
+        call = lambda m, a: fn(m) if a is None else fn(m, a)
+        if not self._cuda:
+            return [call(m, a) for m, a in zip(self.members, args)]
+        cur = torch.cuda.current_stream(self.members[0].device)
+        fork = cur.record_event()
+        outs = []
+        for m, a, st in zip(self.members, args, self._streams):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                outs.append(call(m, a))
+        for st in self._streams:
+            cur.wait_stream(st)
+        return outs
 
     def reset(self, seed=0):
-        outs = [m.reset(seed=seed) for m in self.members]
+        outs = self._each(lambda m: m.reset(seed=seed))
         return [o for o, _ in outs], [i for _, i in outs]
 
     def step(self, actions):
-        outs = [m.step(a) for m, a in zip(self.members, actions)]
+        outs = self._each(lambda m, a: m.step(a), actions)
         return tuple(list(col) for col in zip(*outs))
 
     def sample_random_actions(self, policy_seed=0):
-        return [m.sample_random_actions(policy_seed) for m in self.members]
+        return self._each(lambda m: m.sample_random_actions(policy_seed))
 
     def random_rollout(self, n_steps, policy_seed=0):
-        for m in self.members:
-            m.random_rollout(n_steps, policy_seed)
+        for _ in range(int(n_steps)):  # one vector step of every member at a time: the members stay in lockstep, as with step()
+            self._each(lambda m: m.random_rollout(1, policy_seed))
 
     def close(self):
         for m in self.members:

@@ -26,6 +26,7 @@ def bench_c5(slots_per_id=16384, n_sizes=481, K=100, ids=(0, 1, 2)):
         ns = rng.integers(32, 513, slots_per_id)
         if k not in ids: continue  # (c5sp / c5mis / c5ds: one member alone, same size draw)
         sizes = [(int((ns == n).sum()), int(n), 3 * int(n)) for n in np.unique(ns)]
+        if os.environ.get("GE_C5_PREFETCH"): extra = dict(extra, prefetch=int(os.environ["GE_C5_PREFETCH"]))  # (refill period of the spare images)
         members.append(ge.RaggedVectorEnv(eid, sizes, **extra))
     mixed = ge.MixedVectorEnv(members)
     t0 = time.perf_counter(); mixed.reset(seed=0); torch.cuda.synchronize(); t_reset = time.perf_counter() - t0
