@@ -8,12 +8,12 @@
 #include "ge_params.h"
 #include "ge_platform.h"
 
-// weight code k -> k/10.0 (codes 3..9 = randint(3,10)/10.0, 10 = 1.0 for unweighted graphs)
+// weight code k -> k/10.0 (codes 3..9 = randint(3,10)/10.0, 10 = 1.0 for unweighted graphs; any other code reads as 1.0)
+// One correctly rounded float64 division -- 3 / 10.0 IS the double the literal 0.3 names, and so on -- instead of an eight-way
+// switch: in a loop whose lanes hold different codes the switch is eight masked branches per call.
 GE_DEV double ge_wlut(int code) {
-  switch (code) {
-    case 3: return 0.3; case 4: return 0.4; case 5: return 0.5; case 6: return 0.6;
-    case 7: return 0.7; case 8: return 0.8; case 9: return 0.9; default: return 1.0;
-  }
+  const int k = (code >= 3 && code <= 9) ? code : 10;
+  return (double)k / 10.0;
 }
 
 GE_DEV uint32_t ge_temper(uint32_t y) {
@@ -1215,26 +1215,48 @@ GE_DEV void ge_numpy_wave(const GeParams &P, const GeRctx &c, const uint32_t *mt
 }
 
 // DistributionCenter, n <= 64: nodes within `cutoff` of `s` (float64 sums taken from s outwards), by a label-correcting search
-// of ONE lane: a LIFO stack of nodes to relax over distances S[node * ss] (the least fixpoint does not depend on the order).
-// rowptr / colw may be the LDS copies of the reset kernel or the global slabs; S and stk are the lane's own columns.
+// of ONE lane over distances S[node * ss] -- the least fixpoint does not depend on the order the nodes are relaxed in.  The order is
+// by ROUNDS: the nodes whose label improved in one round (a 64-bit set) are relaxed in the next, so a label is extended about once
+// per hop count that reaches it (cutoff 1.0 over delays 0.3-0.9: four rounds, ~300 row entries per source; the LIFO stack of
+// rounds 2-3 re-relaxed nodes as often as a deeper detour improved them: 106 us of one wave per slot for its 12 targets, the
+// whole "writeout" phase of tools/phase_stamps_any.py).  rowptr / colw may be the LDS copies of the reset kernel or the global
+// slabs; S is the lane's own column (stk / ks: unused scratch of the earlier form, kept in the signature for the callers).
 template <class RP, class CW>
 GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, const CW *colw, double *S, int ss, uint8_t *stk, int ks) {
+  (void)stk; (void)ks;
   for (int v = 0; v < n; v++) S[v * ss] = __builtin_inf();
   S[s * ss] = 0.0;
-  int top = 1; uint64_t instack = 1ull << s, reached = 1ull << s;
-  stk[0] = (uint8_t)s;
-  while (top > 0) {
-    const int u = stk[(--top) * ks];
-    instack &= ~(1ull << u);
-    const double du = S[u * ss];
-    for (int k = rowptr[u]; k < rowptr[u + 1]; k++) {
-      const int v = colw[k] >> 4;
-      const double d = du + ge_wlut(colw[k] & 15);
-      if (d <= cutoff && d < S[v * ss]) {
-        S[v * ss] = d; reached |= 1ull << v;
-        if (!((instack >> v) & 1ull)) { stk[top * ks] = (uint8_t)v; top++; instack |= 1ull << v; }
+  uint64_t reached = 1ull << s, cur = 1ull << s;
+  while (cur) {
+    uint64_t nxt = 0;
+    for (; cur; cur &= cur - 1) {
+      const int u = ge_ctz64(cur);
+      const double du = S[u * ss];
+      const int r1 = rowptr[u + 1];
+      // four row entries per trip: the entries, then the labels they point at, are loaded UNCONDITIONALLY (an entry past the end of
+      // the row re-reads the row's first) and used afterwards (the relaxations of a trip touch different nodes: no parallel edges)
+      for (int k0 = rowptr[u]; k0 < r1; k0 += 4) {
+        uint32_t e[4]; double sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = (uint32_t)colw[k0 + j < r1 ? k0 + j : k0];
+#pragma unroll
+        for (int j = 0; j < 4; j++) sv[j] = S[(int)(e[j] >> 4) * ss];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int v = (int)(e[j] >> 4);
+          const double d = du + ge_wlut((int)(e[j] & 15u));
+          if (k0 + j < r1 && d <= cutoff && d < sv[j]) {
+            S[v * ss] = d; reached |= 1ull << v;
+            // every delay is at least 0.3 (codes 3 .. 10 of ge_wlut) and float64 addition is monotone: a label that cannot be extended
+            // by 0.3 cannot be extended by any entry of its row, so its node is not relaxed again (cutoff 1.0: every label above 0.7,
+            // i.e. most of what lies two or three hops out).  Kept out of the set rather than skipped when it comes up: the lanes of
+            // a wave walk their sets in step, and a trip costs every lane what it costs the one with a row to scan
+            if (d + 0.3 <= cutoff) nxt |= 1ull << v;
+          }
+        }
       }
     }
+    cur = nxt;
   }
   return reached;
 }
@@ -1720,6 +1742,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       ge_wave_sync();
     }
   }
+  GE_STAMP_B0(7);
   if (t == GE_DISTRIBUTION_CENTER) {
     // distribution_center.py:25-26,117-118: nodes within max_distance of every node, each from that node as the source
     // (float sums depend on the direction); the first mask is the union over the targets
@@ -1766,6 +1789,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       ge_wave_sync();
     }
   }
+  GE_STAMP_B0(8);
   for (int w = lane; w < AW; w += GE_WAVE) {
     uint64_t mb;
     int lo = w * 64, hi = lo + 64; if (hi > A) hi = A;

@@ -291,7 +291,9 @@ class VectorGraphEnv(_VectorBase):
         per_step = num_envs / max(length, 1.0)
         if per_step >= 600:
             return 0
-        return int(min(128, max(8, 8192 / max(per_step, 1.0))))
+        # ~2 500 regenerations per refill: on BASELINE config 4 (~70 slots finish per step) the steady state gives 52 / 57 / 60 / 62.6 /
+        # 58.6 / 56 M env-steps/s at periods 4 / 8 / 16 / 32 / 64 / 128 (bench.py --config c4 --prefetch P, value_200)
+        return int(min(128, max(4, 2560 / max(per_step, 1.0))))
 
     def _image_tensors(self, views=None):
         """a second set of the per-slot slabs (ge_spares.image); `views`: slabs given by the caller (multi-class engine)"""

@@ -19,6 +19,7 @@ for B in [int(b) for b in os.environ.get("GE_BS", "1,512").split(",")]:
     for k, nm in names.items():
         nxt = {6: 9, 3: 5}.get(k, k + 1)
         if ts[k] and ts[nxt]: print(f"    {nm:22s} {(ts[nxt]-ts[k])/100:9.1f} us")
-    if ts[3] and ts[7] and ts[8]: print(f"    late draws: wanted cells {(ts[7]-ts[3])/100:.1f} us, stream {(ts[8]-ts[7])/100:.1f} us, rest {(ts[5]-ts[8])/100:.1f} us")
+    if ts[9] and ts[7] and ts[8] and ts[7] > ts[9]: print(f"    writeout: before the range search {(ts[7]-ts[9])/100:.1f} us, range search {(ts[8]-ts[7])/100:.1f} us, rest {(ts[10]-ts[8])/100:.1f} us")
+    elif ts[3] and ts[7] and ts[8]: print(f"    late draws: wanted cells {(ts[7]-ts[3])/100:.1f} us, stream {(ts[8]-ts[7])/100:.1f} us, rest {(ts[5]-ts[8])/100:.1f} us")
     if ts[0] and ts[10]: print(f"    whole slot             {(ts[10]-ts[0])/100:9.1f} us")
     env.close()
