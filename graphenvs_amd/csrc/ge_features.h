@@ -67,9 +67,9 @@ GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat
 // on one node with four entries per trip a level of 150 nodes cost three such chains one after the other (4 400 cycles per level
 // at n = 256, tools/feat_phase_clocks.py).  DELTA false: sigma[v] = sum of front[u] (path counts: integers, exact in any order).
 // DELTA true: delta[v] = sum of sigma[v] * coeff[w] IN ROW ORDER; an entry past the end of the row adds sigma[v] * 0.0 = +0.0.
-template <bool DELTA>
-GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
-  constexpr int U = 2, CH = 8;
+template <bool DELTA, int U>
+GE_DEV void ge_brandes_pull_u(const GeFctx &c, int k0, int k1, int lane) {
+  constexpr int CH = 8;
   for (int kb = k0; kb < k1; kb += U * GE_WAVE) {
     int v[U], e[U], r1[U]; bool on[U]; double acc[U], sv[U];
 #pragma unroll
@@ -79,7 +79,7 @@ GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
     for (int u = 0; u < U; u++) { const int k = kb + u * GE_WAVE + lane; on[u] = k < k1; v[u] = (int)c.ord[on[u] ? k : k0]; }
 #pragma unroll
     for (int u = 0; u < U; u++) { const int a = c.rowptr[v[u]], b = c.rowptr[v[u] + 1]; e[u] = on[u] ? a : 0; r1[u] = on[u] ? b : 0; sv[u] = DELTA ? c.sigma[v[u]] : 1.0; acc[u] = 0.0; }
-    while (e[0] < r1[0] || e[1] < r1[1]) {
+    while (e[0] < r1[0] || (U > 1 && e[U - 1] < r1[U - 1])) {
       int w[U][CH]; double f[U][CH]; bool ok[U][CH];
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -101,6 +101,29 @@ GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
   }
 }
 
+// OR of the adjacency bit rows of the nodes ord[lo .. hi): lane = group * Wp + word, a group takes every NG-th node, eight rows per
+// trip -- unconditional loads from addresses that are always valid, selected afterwards (see ge_brandes_pull_u) -- so the loads of
+// a trip are in flight together.  The caller combines the groups.
+GE_DEV uint64_t ge_level_rows_or(const uint16_t *ord, const uint64_t *rows, int lo, int hi, int gg, int gw, int W, int NG) {
+  uint64_t un = 0;
+  for (int k = lo + gg; k < hi; k += 8 * NG) {
+    int u[8]; uint64_t r[8]; bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ok[j] = k + j * NG < hi && gw < W; u[j] = (int)ord[ok[j] ? k + j * NG : lo]; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint64_t x = rows[u[j] * W + (gw < W ? gw : 0)]; r[j] = ok[j] ? x : 0ull; }
+    un |= ((r[0] | r[1]) | (r[2] | r[3])) | ((r[4] | r[5]) | (r[6] | r[7]));
+  }
+  return un;
+}
+
+// (a level of at most 64 nodes -- the first and the last levels of every search -- takes one row per lane: the kernel is bound by
+// vector-instruction issue, and the second row of a lane costs its instructions whether or not it exists)
+template <bool DELTA>
+GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
+  if (k1 - k0 <= GE_WAVE) ge_brandes_pull_u<DELTA, 1>(c, k0, k1, lane); else ge_brandes_pull_u<DELTA, 2>(c, k0, k1, lane);
+}
+
 GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid_fresh(), nthreads = ge_bdim();
   const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
@@ -115,7 +138,10 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   // (8-32 KB per slot, shared by the slot's nine workgroups: cache hits).
   const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
   const bool node_role = node_part || nparts == 1, brandes_role = !node_part;
-  const uint64_t *arows = G.adj_bits + nbase * W;        // the slot's adjacency bit rows in HBM
+  // the slot's adjacency bit rows in HBM.  (A copy in LDS for the searches, where it costs neither a wave nor a workgroup per CU, was
+  // measured: the same cycles per source at n = 200 / 400 / 512, 26.6 -> 17 K cycles of discovery at n = 256, and config 5 lost a
+  // fifth -- dropped.)
+  const uint64_t *arows = G.adj_bits + nbase * W;
   // stage the slot's graph in LDS
   if (node_role) for (int i = tid; i < n * W; i += nthreads) c.abits[i] = arows[i];
   for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
@@ -162,23 +188,20 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
     int d = 0, reach = 1, lo = 0, hi = 1; int64_t tot = 0;
     for (;;) {
       GE_FSTAMP(0);
-      uint64_t un = 0;
-      for (int k = lo + gg; k < hi; k += 8 * NG) {  // eight rows per trip: the (global) loads of a trip are in flight together
-        int u[8]; uint64_t r[8]; bool ok[8];  // (unconditional loads from addresses that are always valid, selected afterwards: see ge_brandes_pull)
-#pragma unroll
-        for (int j = 0; j < 8; j++) { ok[j] = k + j * NG < hi && gw < W; u[j] = (int)c.ord[ok[j] ? k + j * NG : lo]; }
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const uint64_t x = arows[u[j] * W + (gw < W ? gw : 0)]; r[j] = ok[j] ? x : 0ull; }
-        un |= ((r[0] | r[1]) | (r[2] | r[3])) | ((r[4] | r[5]) | (r[6] | r[7]));
-      }
+      uint64_t un = ge_level_rows_or(c.ord, arows, lo, hi, gg, gw, W, NG);
       for (int off = Wp; off < GE_WAVE; off <<= 1) un |= ge_shfl_u64(un, lane ^ off);
       if (lane < W) { const uint64_t nw = un & ~vis[lane]; vis[lane] |= nw; nxt[lane] = nw; }
       ge_wave_sync();
       int found = 0;
-      for (int w = 0; w < W; w++) {
-        const uint64_t b = nxt[w];
-        if ((b >> lane) & 1ull) c.ord[hi + found + ge_popc64(b & below)] = (uint16_t)(w * GE_WAVE + lane);
-        found += ge_popc64(b);
+      for (int w0 = 0; w0 < W; w0 += 8) {  // eight words of the new level per trip (their reads in flight together)
+        uint64_t b[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) b[j] = nxt[w0 + j < W ? w0 + j : w0];
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (w0 + j < W) {  // (wave-uniform)
+          if ((b[j] >> lane) & 1ull) c.ord[hi + found + ge_popc64(b[j] & below)] = (uint16_t)((w0 + j) * GE_WAVE + lane);
+          found += ge_popc64(b[j]);
+        }
       }
       if (!found) break;
       ge_wave_sync();
