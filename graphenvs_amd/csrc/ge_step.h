@@ -116,11 +116,39 @@ GE_DEV int ge_nth_set_bit(uint64_t word, uint32_t r) {
 }
 
 // the action of slot i under that policy (-1: empty mask, or a frozen slot)
+// up to eight words of a slot's row in one round trip: every load unconditional (a word past the end re-reads word 0) and the
+// words that do not exist zeroed afterwards.  A `for (w < W)` over global memory with a run-time bound is one load, one wait per
+// trip -- ~2 us each at one wave per CU, and the thread-per-slot step kernel of a 512-node class had forty of them in a row.
+GE_DEV void ge_words8(const uint64_t *p, int W, uint64_t (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = p[j < W ? j : 0];
+#pragma unroll
+  for (int j = 0; j < 8; j++) if (j >= W) o[j] = 0ull;
+}
+
 GE_DEV int64_t ge_policy_pick(const GeParams &P, int i, uint64_t policy_seed) {
   const uint64_t *mb = P.buf.mask_bits + (int64_t)i * P.AW;
+  const uint64_t packed = P.buf.slot_rec[2 * (int64_t)i + 1];
+  if (P.AW <= 8) {  // the whole row in registers
+    uint64_t m[8]; ge_words8(mb, P.AW, m);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) cnt += (uint32_t)ge_popc64(m[w]);
+    if (!cnt || ge_rec_status(packed) == 1 || ge_rec_status(packed) == 4) return -1;
+    const uint64_t gi = (uint64_t)(P.env_index_base + i), ts = ge_rec_tstep(packed);
+    const uint64_t z = ge_mix64(policy_seed + gi * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
+    uint32_t r = (uint32_t)(((z >> 32) * (uint64_t)cnt) >> 32);
+    int64_t pick = -1;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const uint32_t pc = (uint32_t)ge_popc64(m[w]);
+      if (pick < 0 && r < pc) pick = (int64_t)w * 64 + ge_nth_set_bit(m[w], r);
+      if (pick < 0) r -= pc;
+    }
+    return pick;
+  }
   uint32_t cnt = 0;
   for (int w = 0; w < P.AW; w++) cnt += (uint32_t)ge_popc64(mb[w]);
-  const uint64_t packed = P.buf.slot_rec[2 * (int64_t)i + 1];
   if (!cnt || ge_rec_status(packed) == 1 || ge_rec_status(packed) == 4) return -1;
   uint64_t gi = (uint64_t)(P.env_index_base + i), ts = ge_rec_tstep(packed);
   uint64_t z = ge_mix64(policy_seed + gi * 0x9E3779B97F4A7C15ull + ts * 0xD1B54A32D192ED03ull);
@@ -205,6 +233,19 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
           uint64_t *const sc_ = (PRUNE == 2) ? G.prune_scratch + (int64_t)i * 4 * W : nullptr;
 #define alive(w) (*(PRUNE == 2 ? &sc_[w] : &la_[w]))
 #define R(w) (*(PRUNE == 2 ? &sc_[W + (w)] : &lr_[w]))
+          if (PRUNE == 0 && W <= 8) {  // the visited set and the chosen node's row in registers, one round trip (ge_words8)
+            uint64_t vb8[8], row8[8];
+            ge_words8(G.node_bits + (int64_t)i * W, W, vb8); ge_words8(G.adj_bits + (nbase + a) * W, W, row8);
+#pragma unroll
+            for (int w = 0; w < 8; w++) if (w < W) {
+              if ((a >> 6) == w) { vb8[w] |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb8[w]; }
+              const uint64_t nm = (lp && P.parenting == 0) ? ge_full_word(A, w) : (row8[w] & ~vb8[w]);
+              stage[tid * WS + w] = nm; any |= nm;
+            }
+            wrote_mask = !(lp && P.parenting == 0);
+            if (!done && !any) { done = 1; solved = 0; reward = lp ? -2.0 * n : -(double)n; }
+            break;
+          }
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
@@ -464,12 +505,30 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
           if (a == n - 1) { reward = 0.0; done = 1; break; }  // stop action: densest_subgraph.py:148-154
           int k = G.counters[i * 2], ecnt = G.counters[i * 2 + 1], new_edges = 0;
           uint64_t any = 0;
+          uint64_t vb8[8], row8[8], un8[8];
+          const bool regs = W <= 8;  // the slot's rows in registers, one round trip (ge_words8)
+          if (regs) {
+            ge_words8(G.node_bits + (int64_t)i * W, W, vb8); ge_words8(G.adj_bits + (nbase + a) * W, W, row8);
+            if (P.parenting != 0) ge_words8(G.target_bits + (int64_t)i * W, W, un8);
+#pragma unroll
+            for (int w = 0; w < 8; w++) new_edges += ge_popc64(row8[w] & vb8[w]);
+          } else
           for (int w = 0; w < W; w++) new_edges += ge_popc64(G.adj_bits[(nbase + a) * W + w] & G.node_bits[(int64_t)i * W + w]);
           reward = (k == 0) ? 0.0 : ((double)(ecnt + new_edges) / (double)(k + 1)) - ((double)ecnt / (double)k);
           ecnt += new_edges; k += 1;
           G.counters[i * 2] = k; G.counters[i * 2 + 1] = ecnt;
           G.x[(nbase + a) * F + 0] = 1.f;
           cost = (double)ecnt / (double)k;
+          if (regs) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) if (w < W) {
+              if ((a >> 6) == w) { vb8[w] |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb8[w]; }
+              uint64_t nm;
+              if (P.parenting == 0) nm = ge_full_word(A, w) & ~vb8[w];
+              else { const uint64_t un = un8[w] | row8[w]; G.target_bits[(int64_t)i * W + w] = un; nm = un & ~vb8[w]; }
+              stage[tid * WS + w] = nm; any |= nm;
+            }
+          } else
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
@@ -495,6 +554,15 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
           reward = (double)r;
           G.x[(nbase + a) * F + 1] = 1.f;
           uint64_t any = 0;
+          if (W <= 8) {
+            uint64_t vb8[8]; ge_words8(G.node_bits + (int64_t)i * W, W, vb8);
+#pragma unroll
+            for (int w = 0; w < 8; w++) if (w < W) {
+              if ((a >> 6) == w) { vb8[w] |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb8[w]; }
+              const uint64_t nm = ge_full_word(A, w) & ~vb8[w];
+              stage[tid * WS + w] = nm; any |= nm;
+            }
+          } else
           for (int w = 0; w < W; w++) {
             uint64_t vb = G.node_bits[(int64_t)i * W + w];
             if ((a >> 6) == w) { vb |= 1ull << (a & 63); G.node_bits[(int64_t)i * W + w] = vb; }
@@ -537,7 +605,21 @@ GE_KERNEL ge_k_step(GeParams PG, GeRagged R, const int64_t *actions, uint64_t po
     if constexpr (RAGGED) {  // the slot's own thread expands its mask words to bool bytes
       if (wrote_mask && !edge_mask) {
         uint8_t *out = G.mask + (int64_t)i * A;
-        for (int v = 0; v < A; v++) out[v] = (uint8_t)((stage[tid * WS + (v >> 6)] >> (v & 63)) & 1ull);
+        // eight bool bytes per store where the row's bytes are 8-aligned (bit k of a byte of the set -> byte k: the multiply spreads
+        // the byte, the mask picks bit k of copy k, the add-and-shift turns "non-zero" into 1), single bytes at the ragged ends
+        int v = 0;
+        const int head_bytes = (int)((8 - ((uintptr_t)out & 7)) & 7);
+        for (; v < A && v < head_bytes; v++) out[v] = (uint8_t)((stage[tid * WS + (v >> 6)] >> (v & 63)) & 1ull);
+        for (; v + 8 <= A; v += 8) {
+          const int w = v >> 6, sh = v & 63;
+          uint64_t b8 = stage[tid * WS + w] >> sh;
+          if (sh > 56 && w + 1 < (A + 63) / 64) b8 |= stage[tid * WS + w + 1] << (64 - sh);
+          b8 &= 0xffull;
+          uint64_t y = (b8 * 0x0101010101010101ull) & 0x8040201008040201ull;
+          y = ((y + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull;
+          *(uint64_t *)(out + v) = y;
+        }
+        for (; v < A; v++) out[v] = (uint8_t)((stage[tid * WS + (v >> 6)] >> (v & 63)) & 1ull);
       }
     }
   }

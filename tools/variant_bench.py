@@ -10,7 +10,10 @@ flags = sys.argv[1].split()
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 out = os.path.join(ROOT, "gpurun_out", "libge_variant.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(_lib.compile_command(out, extra=flags))
+cmd = _lib.compile_command(out, extra=[f for f in flags if not f.startswith("--offload-arch")])
+arch = [f for f in flags if f.startswith("--offload-arch")]  # (a target given here replaces the default one, e.g. gfx950:xnack-)
+if arch: cmd = [arch[0] if c.startswith("--offload-arch") else c for c in cmd]
+subprocess.check_call(cmd)
 L = _lib.bind(C.CDLL(out))
 env = ge.VectorGraphEnv("ShortestPath-v0", 65536, 64, 192, device="cuda", _library=L)
 env.reset(seed=0); env.random_rollout(10, 1); torch.cuda.synchronize()
