@@ -43,6 +43,7 @@ struct ge_engine {
   GeRagged R;
   std::vector<GeParams> classes;  // host copy (ge_vectorize launches per class)
   int feat64_pre_off, gen_pre_off;
+  int lds_bytes_inject;  // GeParams.nocolw engines: ge_inject_state runs the graph kernel on the full LDS carve (the injected rows need the list)
   GeBucket bk[GE_MAX_BUCKETS];
   bool loaded;    // the slots hold an episode (ge_reset or ge_inject_state ran)
   bool seeded;    // the generator-state ring is valid (ge_reset, or ge_inject_state with seeds)
@@ -169,6 +170,7 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   if (!P.complete && m > 65535) return fail(GE_E_TOOBIG, "n_edges > 65535 for a non-complete graph");
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
+  P.nocolw = (t == GE_TSP && P.complete && ng == n && !P.is_eval && !P.spatial && !getenv("GE_KEEP_COLW")) ? 1 : 0;
   ge_make_lds(P, queue_B > 0 ? queue_B : P.B);
   ge_make_ldsf(P, queue_B > 0 ? queue_B : P.B);
   if (P.lds.total > kMaxLds || P.ldsf.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
@@ -248,7 +250,9 @@ static int finish_create(ge_engine *e, ge_engine **out) {
   }
   if (rg && e->P.lds.pre != 0) { e->P.lds.pre = ge_align16(reset_lds); reset_lds = e->P.lds.pre + (nblk + 2) * 4; }  // prefix behind every class's scratch
   e->lds_bytes = reset_lds;
-  if (reset_lds > kMaxLds || gen_lds > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS"); }
+  e->lds_bytes_inject = reset_lds;
+  if (!rg && P.nocolw) { GeParams Pi = P; Pi.nocolw = 0; ge_make_lds(Pi, P.B); e->lds_bytes_inject = Pi.lds.total; }
+  if (reset_lds > kMaxLds || gen_lds > kMaxLds || e->lds_bytes_inject > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS"); }
   int per_cu = kMaxLds / (reset_lds > 0 ? reset_lds : 1);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
@@ -256,9 +260,10 @@ static int finish_create(ge_engine *e, ge_engine **out) {
   if (e->reset_grid > P.B) e->reset_grid = P.B;
   e->nseed = (e->reset_grid + 63) / 64;  // one seeding workgroup per 64 regenerating workgroups: the usual queue fits one round of both
   hipError_t hr = hipSuccess;
-  if (reset_lds > 64 * 1024) {
+  if (reset_lds > 64 * 1024 || e->lds_bytes_inject > 64 * 1024) {
+    const int most = reset_lds > e->lds_bytes_inject ? reset_lds : e->lds_bytes_inject;
     if (rg) GE_FOR_RAGGED_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_reset<ENV, true>), reset_lds));
-    else GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_reset<ENV, false>), reset_lds));
+    else GE_FOR_ENV(P.env_type, hr = (hipError_t)GE_SET_MAX_DYN_LDS((ge_k_reset<ENV, false>), most));
     if (hr != hipSuccess) { delete e; return fail(GE_E_LAUNCH, "cannot raise the dynamic LDS limit of the reset kernel"); }
   }
   // ---- quad-per-slot step kernel of the edge-action envs: its LDS stage (mask rows + node sets of 256 slots) passes 64 KB
@@ -615,6 +620,9 @@ static int launch_reset(ge_engine *e, const GeParams &V, const GeRagged &VR, con
       rc = check_launch("reset kernel");
       first = false;
     }
+  } else if (run.inject && V.nocolw) {  // the injected rows come in the caller's order: this launch keeps the {neighbour, code} list (the full LDS carve)
+    GeParams Vi = V; Vi.nocolw = 0; ge_make_lds(Vi, V.B);
+    GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes_inject, stream, Vi, VR, seeds, run, inj, nseed, -1));
   } else GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed, -1));
   if (rc == GE_OK) rc = check_launch("reset kernel");
   if (rc != GE_OK) return rc;

@@ -64,6 +64,9 @@ struct GeParams {
   int32_t spatial;   // TSP with coordinates and float64 Euclidean weights (sw64 slab)
   int32_t feat_parts;   // n > 64: workgroups sharing one slot's BFS sources in the feature kernel
   int32_t np_early;  // the numpy wave can produce every weight code without the topology (dense delay matrix fits LDS)
+  int32_t nocolw;    // TSP on the complete graph (BASELINE config 3), no is_eval baseline: the reset kernel keeps no {neighbour, code} list
+                     // in LDS -- the neighbour of directed edge idx is a closed form and its code sits in wsort (ascending order IS
+                     // insertion order there): 32 of the 68 KB of a 128-node slot, i.e. four workgroups per CU instead of two
   int32_t cost_off;  // DistributionCenter: byte offset of the node-cost list inside the wm scratch
   uint64_t div_m;    // complete graphs: floor(2^40 / (ng - 1)) + 1, so that idx / (ng - 1) == (idx * div_m) >> 40 for every directed-edge index
   double n_choices;
@@ -130,7 +133,7 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
   L.elist = take((P.complete ? P.n : (P.m > 0 ? P.m : 1)) * 4);  // complete graphs have no sampled edge list (only the n-entry path stack of the multicast baseline lives here)
   L.fill = take(P.n * 4);
   L.rowptr = take((P.n + 1) * 4);
-  L.colw = take((P.E > 0 ? P.E : 1) * 2);
+  L.colw = take((P.nocolw ? 8 : (P.E > 0 ? P.E : 1)) * 2);
   L.wsort = take(P.E > 0 ? P.E : 1);
   L.tmp = take(P.complete ? 16 : (P.E > 0 ? P.E : 1) * 4);
   L.dist = take(P.n * 4);

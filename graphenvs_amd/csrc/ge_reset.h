@@ -272,6 +272,14 @@ GE_DEV int ge_rank_below(const uint64_t *row, int v) {
   return r + ge_popc64(row[v >> 6] & ((1ull << (v & 63)) - 1ull));
 }
 
+// neighbour / weight code of directed edge idx (insertion order) -- from the LDS list, or (GeParams.nocolw: complete graph, every row
+// holds all other nodes in ascending order) the closed form and the code list in ascending-neighbour order
+GE_DEV int ge_list_nbr(const GeParams &P, const GeRctx &c, int idx) {
+  if (P.nocolw) { const int u = (int)(((uint64_t)(uint32_t)idx * P.div_m) >> 40), k = idx - u * (P.ng - 1); return k < u ? k : k + 1; }
+  return (int)(c.colw[idx] >> 4);
+}
+GE_DEV int ge_list_code(const GeParams &P, const GeRctx &c, int idx) { return P.nocolw ? (int)c.wsort[idx] : (int)(c.colw[idx] & 15); }
+
 // source node of directed edge idx
 GE_DEV int ge_row_of(const GeParams &P, const GeRctx &c, int idx) {
   return P.complete ? (int)(((uint64_t)(uint32_t)idx * P.div_m) >> 40) : (int)c.tmp[idx];  // complete: every row has ng - 1 entries
@@ -1488,7 +1496,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
     }
     ge_wave_sync();
   } else if (P.complete) {
-    for (int idx = lane; idx < E; idx += GE_WAVE) {
+    if (!P.nocolw) for (int idx = lane; idx < E; idx += GE_WAVE) {
       const int u = ge_row_of(P, c, idx), k = idx - u * (ng - 1);
       int v = k < u ? k : k + 1;
       c.colw[idx] = (uint16_t)((v << 4) | 10);
@@ -1544,7 +1552,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       // complete graph ([nx] complete_graph = combinations(nodes, 2)): G.edges is (0,1) (0,2) .. (0,n-1) (1,2) ..., so the edge
       // (a, b), a < b, is draw number a (n - 1) - a (a - 1) / 2 + (b - a - 1): no scan over the edge list
       for (int idx = lane; idx < E; idx += GE_WAVE) {
-        const int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
+        const int u = ge_row_of(P, c, idx), v = ge_list_nbr(P, c, idx);
         const int a = u < v ? u : v, b = u < v ? v : u;
         c.wsort[ge_sorted_pos_p(P, c, u, v)] = ((const uint8_t *)c.wm)[a * (ng - 1) - ((a * (a - 1)) >> 1) + (b - a - 1)];
       }
@@ -1572,7 +1580,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       if (P.buf.stream_state) ge_mt_save(keep_at(1), c.mt2, nppos, lane);
     }
     ge_wave_sync();
-    for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
+    if (!P.nocolw) for (int idx = lane; idx < E; idx += GE_WAVE) {  // codes from ascending order back to insertion order
       int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4;
       c.colw[idx] = (uint16_t)((v << 4) | c.wsort[ge_sorted_pos_p(P, c, u, v)]);
     }
@@ -1692,14 +1700,14 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
     }
   }
   for (int idx = lane; idx < E; idx += GE_WAVE) {
-    int u = ge_row_of(P, c, idx), v = c.colw[idx] >> 4, code = c.colw[idx] & 15;
+    int u = ge_row_of(P, c, idx), v = ge_list_nbr(P, c, idx), code = ge_list_code(P, c, idx);
     G.edge_index[ebase + idx] = P.node_id_base + nbase + u;
     G.edge_index[Ne + ebase + idx] = P.node_id_base + nbase + v;
     float wv = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 1.f : (float)ge_wlut(code);
     if (P.spatial) wv = (float)G.sw64[ebase + ge_sorted_pos_p(P, c, u, v)];
     if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
     else G.edge_attr[ebase + idx] = wv;
-    G.colw[ebase + idx] = c.colw[idx];
+    G.colw[ebase + idx] = (uint16_t)((v << 4) | code);
     G.scode[ebase + idx] = c.wsort[idx];
     if (G.rev_edge) { int r = -1; for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) if ((c.colw[k] >> 4) == u) { r = k; break; } G.rev_edge[ebase + idx] = r; }
   }

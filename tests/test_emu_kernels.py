@@ -244,7 +244,8 @@ def test_emulated_ragged_mixed_batch_matches_oracle(emu):
                                        ("MulticastRouting-v0", dict(n_nodes=12, n_edges=30, n_dests=3)),
                                        ("MulticastRouting-v0", dict(n_nodes=12, n_edges=30, n_dests=3, parenting=2)),
                                        ("DistributionCenter-v0", dict(n_nodes=15, n_edges=40)),
-                                       ("PerishableProductDelivery-v0", dict(n_nodes=12, n_edges=30, parenting=1))])
+                                       ("PerishableProductDelivery-v0", dict(n_nodes=12, n_edges=30, parenting=1)),
+                                       ("TSP-v0", dict(n_nodes=8, n_edges=28, parenting=1))])  # complete graph: the engine's reset kernel keeps no edge list in LDS, the inject launch does
 def test_emulated_inject_state_then_step(emu, env_id, kw):
     import oracle
     from inject_check import check_inject
