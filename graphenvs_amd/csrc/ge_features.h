@@ -44,6 +44,9 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
 // betweenness partial sums are combined in wave order, then clustering and pagerank.
 // nparts > 1: the slot's BFS sources are dealt over nparts workgroups (part 0 .. nparts-1), and ONE MORE workgroup
 // (part == nparts) does the node-level work -- clustering, pagerank, degrees -- beside them instead of behind one of them.
+#ifndef GE_PR_CH
+#define GE_PR_CH 4  // row entries of a pagerank trip (their loads in flight together)
+#endif
 #ifndef GE_FABL
 #define GE_FABL 0  // diagnostic ablation bits of the generic feature kernel (tools/variant_reset.py; the results are wrong by construction): 1 forward
                    // push, 2 backward coefficient pass, 4 backward pull, 8 pagerank iterations; 0 when shipped
@@ -280,9 +283,12 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
     int i = k0 + lane;
     ndang += ge_popc64(ge_ballot(i < n && c.rowptr[i + 1] == c.rowptr[i]));
   }
+  double *wl = (double *)(ge_dyn_smem() + P.ldsf.wl);  // weight of a code: a table read per row entry instead of a division
+  if (tid < 16) wl[tid] = ge_wlut(tid);
+  ge_sync();
   for (int i = tid; i < n; i += nthreads) {
     double S = 0.0;
-    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : ge_wlut(c.scw[k] & 15)) : 1.0) * 1.0;
+    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : wl[c.scw[k] & 15]) : 1.0) * 1.0;
     c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
     c.prx[i] = pinit;
   }
@@ -294,10 +300,22 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
     if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
     for (int i = tid; i < n; i += nthreads) {
       double acc = 0.0;
-      for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
-        int j = c.scw[k] >> 4;
-        double dat = c.sinv[j] * (prw ? (P.spatial ? G.sw64[ebase + k] : ge_wlut(c.scw[k] & 15)) : 1.0);
-        acc += dat * c.prx[j];
+      // GE_PR_CH row entries per trip, every load unconditional (an entry past the end of the row re-reads its first) and the terms
+      // added in row order afterwards: the entry, then sinv / x / the weight it points at, are two LDS round trips per TRIP where
+      // the entry-by-entry loop paid two per entry (a complete 128-node graph: 127 entries per row, ~25 iterations)
+      const int r0 = c.rowptr[i], r1 = c.rowptr[i + 1];
+      for (int k0 = r0; k0 < r1; k0 += GE_PR_CH) {
+        uint32_t e8[GE_PR_CH]; double sv[GE_PR_CH], xv[GE_PR_CH], wv[GE_PR_CH];
+#pragma unroll
+        for (int q = 0; q < GE_PR_CH; q++) e8[q] = (uint32_t)c.scw[k0 + q < r1 ? k0 + q : r0];
+#pragma unroll
+        for (int q = 0; q < GE_PR_CH; q++) {
+          const int j = (int)(e8[q] >> 4);
+          sv[q] = c.sinv[j]; xv[q] = c.prx[j];
+          wv[q] = prw ? (P.spatial ? G.sw64[ebase + (k0 + q < r1 ? k0 + q : r0)] : wl[e8[q] & 15u]) : 1.0;
+        }
+#pragma unroll
+        for (int q = 0; q < GE_PR_CH; q++) if (k0 + q < r1) acc += (sv[q] * wv[q]) * xv[q];
       }
       double xn = alpha * (acc + dsum * pinit) + oma * pinit;
       c.prn[i] = xn;

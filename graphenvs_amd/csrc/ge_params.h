@@ -55,6 +55,7 @@ struct GeLdsF {
   int wave0, wave_stride, waves;       // per-wave areas of the Brandes role
   int w_sigma, w_ord, w_lvl;           // offsets inside a per-wave area (the node sets are at 0; delta, coeff, bcw follow sigma)
   int node, abits, scw, prx, clus;     // node role: abits, scw, then prx, prn, sinv, diff (float64[n] each), clus
+  int wl;                              // node role: the 16 weights k / 10.0 by code (weighted pagerank reads one per row entry and iteration)
   int pre, total;
 };
 
@@ -193,6 +194,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   L.scw = P.complete ? L.colw : take(E * 2);  // [nx] complete_graph: the rows are already in ascending order
   L.prx = take(4 * ge_align16(n * 8));          // prx, prn, sinv, diff
   L.clus = take(n * 8);
+  L.wl = take(16 * 8);
   if (o < waves_end) o = waves_end;
   L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
   L.total = o;
