@@ -147,8 +147,13 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   const uint64_t *arows = G.adj_bits + nbase * W;
   // stage the slot's graph in LDS
   if (node_role) for (int i = tid; i < n * W; i += nthreads) c.abits[i] = arows[i];
+  // complete graph on all n nodes: row i holds every other node in ascending order -- entry q of the row is node q (q < i) or q + 1 --
+  // and only the weight codes are staged, a byte each (scode: ascending-neighbour order)
+  const bool closed = P.complete && P.ng == n;
+  uint8_t *c8 = (uint8_t *)c.colw;
   for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
-  for (int idx = tid; idx < E; idx += nthreads) c.colw[idx] = G.colw[ebase + idx];
+  if (closed) { for (int idx = tid; idx < E; idx += nthreads) c8[idx] = G.scode[ebase + idx]; }
+  else for (int idx = tid; idx < E; idx += nthreads) c.colw[idx] = G.colw[ebase + idx];
   ge_sync();
   // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row (complete graphs: scw IS colw)
   if (node_role && !P.complete) for (int v = tid; v < n; v += nthreads)
@@ -271,7 +276,11 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   double *clus = c.clus;
   for (int i = tid; i < n; i += nthreads) {
     int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
-    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) { int j = c.colw[k] >> 4; for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]); }
+    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
+      int j;
+      if (closed) { const int q = k - c.rowptr[i]; j = q < i ? q : q + 1; } else j = c.colw[k] >> 4;
+      for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]);
+    }
     int64_t t8 = 8 * common, dt = 2 * dg, db = dg;
     clus[i] = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
   }
@@ -288,7 +297,7 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   ge_sync();
   for (int i = tid; i < n; i += nthreads) {
     double S = 0.0;
-    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : wl[c.scw[k] & 15]) : 1.0) * 1.0;
+    for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) S += (prw ? (P.spatial ? G.sw64[ebase + k] : wl[closed ? (int)c8[k] : (int)(c.scw[k] & 15)]) : 1.0) * 1.0;
     c.sinv[i] = (S != 0.0) ? 1.0 / S : 0.0;
     c.prx[i] = pinit;
   }
@@ -305,14 +314,17 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
       // the entry-by-entry loop paid two per entry (a complete 128-node graph: 127 entries per row, ~25 iterations)
       const int r0 = c.rowptr[i], r1 = c.rowptr[i + 1];
       for (int k0 = r0; k0 < r1; k0 += GE_PR_CH) {
-        uint32_t e8[GE_PR_CH]; double sv[GE_PR_CH], xv[GE_PR_CH], wv[GE_PR_CH];
-#pragma unroll
-        for (int q = 0; q < GE_PR_CH; q++) e8[q] = (uint32_t)c.scw[k0 + q < r1 ? k0 + q : r0];
+        int jn[GE_PR_CH], cd[GE_PR_CH]; double sv[GE_PR_CH], xv[GE_PR_CH], wv[GE_PR_CH];
 #pragma unroll
         for (int q = 0; q < GE_PR_CH; q++) {
-          const int j = (int)(e8[q] >> 4);
-          sv[q] = c.sinv[j]; xv[q] = c.prx[j];
-          wv[q] = prw ? (P.spatial ? G.sw64[ebase + (k0 + q < r1 ? k0 + q : r0)] : wl[e8[q] & 15u]) : 1.0;
+          const int kk = k0 + q < r1 ? k0 + q : r0;
+          if (closed) { const int qq = kk - r0; jn[q] = qq < i ? qq : qq + 1; cd[q] = (int)c8[kk]; }
+          else { const uint32_t e = (uint32_t)c.scw[kk]; jn[q] = (int)(e >> 4); cd[q] = (int)(e & 15u); }
+        }
+#pragma unroll
+        for (int q = 0; q < GE_PR_CH; q++) {
+          sv[q] = c.sinv[jn[q]]; xv[q] = c.prx[jn[q]];
+          wv[q] = prw ? (P.spatial ? G.sw64[ebase + (k0 + q < r1 ? k0 + q : r0)] : wl[cd[q]]) : 1.0;
         }
 #pragma unroll
         for (int q = 0; q < GE_PR_CH; q++) if (k0 + q < r1) acc += (sv[q] * wv[q]) * xv[q];

@@ -161,7 +161,9 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   const int n = P.n, E = P.E > 0 ? P.E : 1;
   const bool split = P.feat_parts > 1;  // the Brandes role and the node role are different workgroups
   L.rowptr = take((n + 1) * 4);
-  L.colw = take(E * 2);
+  // (a complete graph on all n nodes keeps one weight-code BYTE per row entry, ascending-neighbour order, instead of the {neighbour,
+  // code} list: the neighbour is a closed form -- half the LDS of BASELINE config 3's slot, twice the workgroups per CU)
+  L.colw = take((P.complete && P.ng == n) ? E : E * 2);
   L.bc = take(n * 8);
   L.clos = take(n * 8);
   const int common = o;

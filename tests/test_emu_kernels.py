@@ -157,7 +157,7 @@ def test_emulated_fused_rollout_equals_sample_then_step(emu, env_id, kw):
 def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep(stress):
     """-DGE_F64_LV=3 forces the lane-per-source path to hand deep slots to the generic kernel."""
     lib = stress
-    for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1"]:
+    for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1", "tsp_n8_m28_p1", "dc_n8_m28_complete_dist0p6"]:  # (the last two: complete graphs, whose rows the generic kernel does not stage)
         case = gu.load_case(name)
         gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
