@@ -171,6 +171,7 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   if (P.E > (1 << 24)) return fail(GE_E_TOOBIG, "too many edges");
   if (cfg->num_envs > 8192 * GE_STEP_BLOCK) return fail(GE_E_TOOBIG, "num_envs > 2M per engine");
   P.nocolw = (t == GE_TSP && P.complete && ng == n && !P.is_eval && !P.spatial && !getenv("GE_KEEP_COLW")) ? 1 : 0;
+  P.nowsort = (P.nocolw && n > 64) ? 1 : 0;
   ge_make_lds(P, queue_B > 0 ? queue_B : P.B);
   ge_make_ldsf(P, queue_B > 0 ? queue_B : P.B);
   if (P.lds.total > kMaxLds || P.ldsf.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
@@ -251,7 +252,7 @@ static int finish_create(ge_engine *e, ge_engine **out) {
   if (rg && e->P.lds.pre != 0) { e->P.lds.pre = ge_align16(reset_lds); reset_lds = e->P.lds.pre + (nblk + 2) * 4; }  // prefix behind every class's scratch
   e->lds_bytes = reset_lds;
   e->lds_bytes_inject = reset_lds;
-  if (!rg && P.nocolw) { GeParams Pi = P; Pi.nocolw = 0; ge_make_lds(Pi, P.B); e->lds_bytes_inject = Pi.lds.total; }
+  if (!rg && P.nocolw) { GeParams Pi = P; Pi.nocolw = 0; Pi.nowsort = 0; ge_make_lds(Pi, P.B); e->lds_bytes_inject = Pi.lds.total; }
   if (reset_lds > kMaxLds || gen_lds > kMaxLds || e->lds_bytes_inject > kMaxLds) { delete e; return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS"); }
   int per_cu = kMaxLds / (reset_lds > 0 ? reset_lds : 1);
   if (per_cu > 16) per_cu = 16;
@@ -621,7 +622,7 @@ static int launch_reset(ge_engine *e, const GeParams &V, const GeRagged &VR, con
       first = false;
     }
   } else if (run.inject && V.nocolw) {  // the injected rows come in the caller's order: this launch keeps the {neighbour, code} list (the full LDS carve)
-    GeParams Vi = V; Vi.nocolw = 0; ge_make_lds(Vi, V.B);
+    GeParams Vi = V; Vi.nocolw = 0; Vi.nowsort = 0; ge_make_lds(Vi, V.B);
     GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes_inject, stream, Vi, VR, seeds, run, inj, nseed, -1));
   } else GE_FOR_ENV(V.env_type, GE_LAUNCH((ge_k_reset<ENV, false>), grid, GE_RESET_THREADS, e->lds_bytes, stream, V, VR, seeds, run, inj, nseed, -1));
   if (rc == GE_OK) rc = check_launch("reset kernel");

@@ -68,6 +68,8 @@ struct GeParams {
   int32_t nocolw;    // TSP on the complete graph (BASELINE config 3), no is_eval baseline: the reset kernel keeps no {neighbour, code} list
                      // in LDS -- the neighbour of directed edge idx is a closed form and its code sits in wsort (ascending order IS
                      // insertion order there): 32 of the 68 KB of a 128-node slot, i.e. four workgroups per CU instead of two
+  int32_t nowsort;   // ... and above 64 nodes (no node_rec to fill) no per-entry code list either: the code of edge (a, b), a < b, is
+                     // draw number a (n - 1) - a (a - 1) / 2 + (b - a - 1) of the numpy wave's byte list -- 20 KB per slot, eight workgroups
   int32_t cost_off;  // DistributionCenter: byte offset of the node-cost list inside the wm scratch
   uint64_t div_m;    // complete graphs: floor(2^40 / (ng - 1)) + 1, so that idx / (ng - 1) == (idx * div_m) >> 40 for every directed-edge index
   double n_choices;
@@ -135,7 +137,7 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
   L.fill = take(P.n * 4);
   L.rowptr = take((P.n + 1) * 4);
   L.colw = take((P.nocolw ? 8 : (P.E > 0 ? P.E : 1)) * 2);
-  L.wsort = take(P.E > 0 ? P.E : 1);
+  L.wsort = take(P.nowsort ? 16 : (P.E > 0 ? P.E : 1));
   L.tmp = take(P.complete ? 16 : (P.E > 0 ? P.E : 1) * 4);
   L.dist = take(P.n * 4);
   L.perm = take(P.n * 4);

@@ -278,7 +278,15 @@ GE_DEV int ge_list_nbr(const GeParams &P, const GeRctx &c, int idx) {
   if (P.nocolw) { const int u = (int)(((uint64_t)(uint32_t)idx * P.div_m) >> 40), k = idx - u * (P.ng - 1); return k < u ? k : k + 1; }
   return (int)(c.colw[idx] >> 4);
 }
-GE_DEV int ge_list_code(const GeParams &P, const GeRctx &c, int idx) { return P.nocolw ? (int)c.wsort[idx] : (int)(c.colw[idx] & 15); }
+GE_DEV int ge_list_code(const GeParams &P, const GeRctx &c, int idx) {
+  if (P.nowsort) {  // straight from the numpy wave's byte list: draw number of the undirected edge (complete_graph = combinations(nodes, 2))
+    if (!P.weighted) return 10;
+    const int u = (int)(((uint64_t)(uint32_t)idx * P.div_m) >> 40), k = idx - u * (P.ng - 1), v = k < u ? k : k + 1;
+    const int a = u < v ? u : v, b = u < v ? v : u;
+    return (int)((const uint8_t *)c.wm)[a * (P.ng - 1) - ((a * (a - 1)) >> 1) + (b - a - 1)];
+  }
+  return P.nocolw ? (int)c.wsort[idx] : (int)(c.colw[idx] & 15);
+}
 
 // source node of directed edge idx
 GE_DEV int ge_row_of(const GeParams &P, const GeRctx &c, int idx) {
@@ -1530,7 +1538,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
   if (!run.inject && t != GE_PERISHABLE_DELIVERY) ge_sync();  // join: the numpy wave's codes and terminals are in LDS
   // ------------------------------------------------------------------ weight codes + terminals
   if (!run.inject) {
-    for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
+    if (!P.nowsort) for (int idx = lane; idx < E; idx += GE_WAVE) c.wsort[idx] = 10;
     ge_wave_sync();
     const bool path_like = path_like_t;
     const bool matrix_w = path_like_t || t == GE_DISTRIBUTION_CENTER || t == GE_PERISHABLE_DELIVERY;  // delay[u, v] of an n x n randint matrix
@@ -1551,7 +1559,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
     } else if (P.weighted && t == GE_TSP && P.complete) {
       // complete graph ([nx] complete_graph = combinations(nodes, 2)): G.edges is (0,1) (0,2) .. (0,n-1) (1,2) ..., so the edge
       // (a, b), a < b, is draw number a (n - 1) - a (a - 1) / 2 + (b - a - 1): no scan over the edge list
-      for (int idx = lane; idx < E; idx += GE_WAVE) {
+      if (!P.nowsort) for (int idx = lane; idx < E; idx += GE_WAVE) {
         const int u = ge_row_of(P, c, idx), v = ge_list_nbr(P, c, idx);
         const int a = u < v ? u : v, b = u < v ? v : u;
         c.wsort[ge_sorted_pos_p(P, c, u, v)] = ((const uint8_t *)c.wm)[a * (ng - 1) - ((a * (a - 1)) >> 1) + (b - a - 1)];
@@ -1708,7 +1716,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
     if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
     else G.edge_attr[ebase + idx] = wv;
     G.colw[ebase + idx] = (uint16_t)((v << 4) | code);
-    G.scode[ebase + idx] = c.wsort[idx];
+    G.scode[ebase + idx] = P.nowsort ? (uint8_t)code : c.wsort[idx];  // (complete graph: ascending-neighbour order is insertion order)
     if (G.rev_edge) { int r = -1; for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) if ((c.colw[k] >> 4) == u) { r = k; break; } G.rev_edge[ebase + idx] = r; }
   }
   for (int v = lane; v <= n; v += GE_WAVE) G.row_ptr[(int64_t)env * (n + 1) + v] = c.rowptr[v];

@@ -252,6 +252,28 @@ def test_emulated_inject_state_then_step(emu, env_id, kw):
     check_inject(ge, oracle, "cpu", env_id, kw, library=emu)
 
 
+def test_emulated_complete_graph_tsp_above_64_nodes_keeps_no_edge_lists_in_lds(emu):
+    """TSP on the complete graph, n > 64 (BASELINE config 3's shape): the reset kernel holds neither the {neighbour, code} list nor
+    the per-entry code list in LDS (GeParams.nocolw / nowsort), the generic feature kernel stages code bytes only"""
+    import oracle
+    kw, B = dict(n_nodes=66, n_edges=66 * 65 // 2, parenting=1), 2
+    env = ge.VectorGraphEnv("TSP-v0", B, device="cpu", _library=emu, seed_stride=1000, env_index_base=3, prefetch=0, obs_mode="flat", **kw)
+    env.reset(seed=5)
+    refs = [oracle.OracleEnv("TSP-v0", **kw) for _ in range(B)]
+    for i, r in enumerate(refs):
+        r.reset(seed=5 + 3 + i)
+    flat = env.flat_obs().numpy()
+    for i, r in enumerate(refs):
+        assert np.array_equal(flat[i], r.obs()), i
+    for k in range(3):
+        a = env.sample_random_actions(policy_seed=9).clone().numpy()
+        _, rew, term, _, info = env.step(a)
+        for i, r in enumerate(refs):
+            _, rr, dd, _, _ = r.step(int(a[i]))
+            assert float(rew[i]) == rr and bool(term[i]) == dd and np.array_equal(info["mask"][i].numpy(), r.mask()), (k, i)
+    env.close()
+
+
 def test_emulated_next_step_autoreset(emu):
     import oracle
     gu.check_next_step_autoreset(ge, oracle, "ShortestPath-v0", dict(n_nodes=10, n_edges=20), 5, 40, "cpu", lib=emu)
