@@ -141,7 +141,11 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
   L.tmp = take(P.complete ? 16 : (P.E > 0 ? P.E : 1) * 4);
   L.dist = take(P.n * 4);
   L.perm = take(P.n * 4);
-  { int need = 2 * P.n * 8, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
+  { // the two float64 node arrays are the Dijkstra / Prim / placement scratch of the is_eval baselines and of the envs that measure
+    // distances at reset (MulticastRouting's delay bound, DistributionCenter's ranges, PerishableProductDelivery's windows); everybody
+    // else only stages the first mask words there -- 8 KB of a 512-node ShortestPath slot, which is what kept it above half a CU's LDS
+    const bool dist_env = P.env_type == GE_MULTICAST_ROUTING || P.env_type == GE_DISTRIBUTION_CENTER || P.env_type == GE_PERISHABLE_DELIVERY;
+    int need = (P.is_eval || dist_env) ? 2 * P.n * 8 : 0, mw = ((P.E > P.n ? P.E : P.n) / 64 + 2) * 8; L.f64a = take(need > mw ? need : mw); }
   L.bits = take(6 * P.W * 8);
   L.misc = take(16 * 4);
   L.fw = (P.env_type == GE_PERISHABLE_DELIVERY && P.n <= 128) ? take(P.n * P.n * 8) : 0;  // (larger graphs: distances per pickup, ge_ppd_place_wide)
