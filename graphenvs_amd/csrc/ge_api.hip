@@ -651,9 +651,12 @@ static int invalidate_spares(ge_engine *e, void *stream) {
   return (e->seeded && e->P.autoreset) ? refill_spares(e, stream) : GE_OK;
 }
 
-static int clear_queue(ge_engine *e, void *stream) {  // a full reset / injection leaves the finished-slot queue empty
+// a full reset / injection leaves the finished-slot queues empty: the regeneration queue and, with spares, the swap queue (next-step
+// autoreset consumes it at the START of the next ge_step: a stale entry would copy an image over the slot that was just reset)
+static int clear_queue(ge_engine *e, void *stream) {
   const size_t bytes = sizeof(int32_t) * (size_t)((e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK);
   if (hipMemsetAsync(e->P.buf.reset_count, 0, bytes, (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
+  if (e->spares && hipMemsetAsync(e->P.swap_count, 0, bytes, (hipStream_t)stream) != hipSuccess) return fail(GE_E_LAUNCH, "hipMemsetAsync failed");
   return GE_OK;
 }
 

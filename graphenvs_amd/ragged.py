@@ -187,7 +187,7 @@ class MixedVectorEnv:
         self.num_envs = sum(m.num_envs for m in self.members)
         dev = getattr(self.members[0], "device", None)
         self._cuda = concurrent and dev is not None and torch.device(dev).type == "cuda" and len(self.members) > 1
-        self._streams = [torch.cuda.Stream(device=dev) for _ in self.members] if self._cuda else None
+        self._streams = [torch.cuda.Stream(device=m.device) for m in self.members] if self._cuda else None
 
     def _each(self, fn, args=None):
         """fn(member[, arg]) for every member: on the member's own stream between a fork from and a join on the current stream"""
@@ -204,6 +204,22 @@ class MixedVectorEnv:
                 outs.append(call(m, a))
         for st in self._streams:
             cur.wait_stream(st)
+        # tensors a member allocated inside its call (sampled actions, copy_outputs clones) belong to the side stream's pool: tell the
+        # caching allocator that the caller's stream uses them too, or a free followed by a direct call on a member could reuse the
+        # memory while the caller's stream still reads it
+        def mark(v):
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+            elif isinstance(v, dict):
+                for x in v.values():
+                    mark(x)
+            elif isinstance(v, (tuple, list)):
+                for x in v:
+                    mark(x)
+            elif hasattr(v, "__dict__") and not callable(v):
+                for x in vars(v).values():
+                    mark(x)
+        mark(outs)
         return outs
 
     def reset(self, seed=0):

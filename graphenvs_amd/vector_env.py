@@ -293,7 +293,11 @@ class VectorGraphEnv(_VectorBase):
             return 0
         # ~2 500 regenerations per refill: on BASELINE config 4 (~70 slots finish per step) the steady state gives 52 / 57 / 60 / 62.6 /
         # 58.6 / 56 M env-steps/s at periods 4 / 8 / 16 / 32 / 64 / 128 (bench.py --config c4 --prefetch P, value_200)
-        return int(min(128, max(4, 2560 / max(per_step, 1.0))))
+        # ... but never longer than about half an episode: a slot that finishes again before the refill takes the (throttled) path
+        # in place, and with short episodes every refill would regenerate about every image anyway (DistributionCenter at 1 000
+        # slots: 15 -> 3; ShortestPath n = 10 at 256 slots: 39 -> 2)
+        period = min(128.0, max(4.0, 2560 / max(per_step, 1.0)), max(2.0, length / 2))
+        return int(period)
 
     def _image_tensors(self, views=None):
         """a second set of the per-slot slabs (ge_spares.image); `views`: slabs given by the caller (multi-class engine)"""
@@ -528,6 +532,21 @@ class VectorGraphEnv(_VectorBase):
                 dict.__getitem__(self.t, k).copy_(v)
         if self.spare is not None:
             self.spare["state"].zero_()  # every image is regenerated at the next opportunity
+            # next-step autoreset: a slot that finished in the snapshot's last step waits for its regeneration (status 2), queued
+            # either for the regeneration in place (reset_list, part of the snapshot) or -- it had a valid image -- for the swap
+            # (swap_list, which is not: the images are gone).  Every such slot goes through the regeneration queue, in the layout the
+            # step kernels write (a segment per 256 slots, slot order), and this engine's own swap queue is emptied.
+            self.spare["swap_count"].zero_()
+            B = self.num_envs
+            fin = (self.t["status"] == 2).to(torch.int32)
+            pad = torch.zeros(((B + 255) // 256) * 256, dtype=torch.int32, device=self.device)
+            pad[:B] = fin
+            blocks = pad.view(-1, 256)
+            rank = torch.cumsum(blocks, dim=1) - blocks
+            slot = torch.arange(pad.numel(), device=self.device, dtype=torch.int32).view(-1, 256)
+            pos = (slot - slot % 256 + rank)[blocks.bool()].to(torch.int64)
+            dict.__getitem__(self.t, "reset_list")[pos] = slot[blocks.bool()]
+            dict.__getitem__(self.t, "reset_count").copy_(blocks.sum(dim=1).to(torch.int32))
         _lib.check(self._L, self._L.ge_mark_restored(self._h), "ge_mark_restored")
         self._was_reset = True
         self._streams = self.continue_streams and "stream_state" in sd

@@ -144,3 +144,66 @@ def check_continue_streams(ge, oracle, device, lib):
         assert env.t["seed"].cpu().numpy().view(np.uint32).tolist() == seeds
         env.check_device_errors()
         env.close()
+
+
+_LIVE = ("reward", "terminated", "mask", "mask_bits", "slot_rec", "node_bits", "episode", "seed", "x", "edge_index", "edge_attr", "heuristic",
+         "final_cost", "final_heur", "final_len", "solved")
+
+
+def _same_live(a, b, where):
+    a._quiesce(); b._quiesce()
+    for key in _LIVE:
+        assert torch.equal(a.t[key], b.t[key]), (where, key)
+
+
+def check_prefetch_reset_mid_rollout(ge, device, lib, mode):
+    """reset() / inject-free restart in the middle of a rollout of an engine with spares.  With next-step autoreset the
+    swap queue of the last step is consumed at the START of the next ge_step: a reset in between must empty it, or the image of
+    episode 1 is copied over the slot that was just reset.  Compared with the engine without spares, slab by slab."""
+    kw = dict(n_nodes=6, n_edges=9, obs_mode="flat", autoreset=mode, seed_stride=100, **_extra(device, lib))
+    a = ge.VectorGraphEnv("ShortestPath-v0", 8, prefetch=3, **kw)
+    b = ge.VectorGraphEnv("ShortestPath-v0", 8, prefetch=0, **kw)
+    a.reset(seed=5); b.reset(seed=5)
+    hit = False
+    for k in range(12):  # step until some slot has just terminated with a valid image, then reset
+        valid = a.spare["state"].clone()
+        a.random_rollout(1, policy_seed=2); b.random_rollout(1, policy_seed=2)
+        _same_live(a, b, ("before", k))
+        if bool(((a.t["terminated"] != 0) & (valid.to(a.t["terminated"].device) != 0)).any()) and k >= 2:
+            hit = True
+            break
+    assert hit
+    a.reset(seed=77); b.reset(seed=77)
+    _same_live(a, b, "reset")
+    for k in range(10):
+        a.random_rollout(1, policy_seed=3); b.random_rollout(1, policy_seed=3)
+        _same_live(a, b, ("after", k))
+    assert int(a.t["episode"].sum()) > 0
+    a.close(); b.close()
+
+
+def check_prefetch_state_dict_next_step(ge, device, lib):
+    """a snapshot of an engine with spares in next-step mode, taken right after a step in which slots finished with a valid
+    image (they wait in the swap queue, which is not state): restored into a fresh engine with spares -- whose own swap queue holds
+    entries of an earlier rollout -- every such slot is regenerated, and nothing else is."""
+    kw = dict(n_nodes=6, n_edges=9, obs_mode="flat", autoreset="next_step", seed_stride=100, **_extra(device, lib))
+    a = ge.VectorGraphEnv("ShortestPath-v0", 8, prefetch=3, **kw)
+    ref = ge.VectorGraphEnv("ShortestPath-v0", 8, prefetch=0, **kw)
+    a.reset(seed=5); ref.reset(seed=5)
+    hit = False
+    for k in range(12):
+        valid = a.spare["state"].clone()
+        a.random_rollout(1, policy_seed=2); ref.random_rollout(1, policy_seed=2)
+        if bool(((a.t["terminated"] != 0) & (valid.to(a.t["terminated"].device) != 0)).any()) and k >= 2:
+            hit = True
+            break
+    assert hit
+    sd = a.state_dict()
+    b = ge.VectorGraphEnv("ShortestPath-v0", 8, prefetch=3, **kw)
+    b.reset(seed=900); b.random_rollout(7, policy_seed=9)  # leaves stale entries in its own queues
+    b.load_state_dict(sd)
+    for k in range(12):
+        b.random_rollout(1, policy_seed=2); ref.random_rollout(1, policy_seed=2)
+        _same_live(b, ref, k)
+    assert int(b.t["episode"].min()) > 0
+    a.close(); b.close(); ref.close()

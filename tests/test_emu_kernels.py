@@ -294,6 +294,15 @@ def test_emulated_state_dict_moves_between_engines(emu):
     hc.check_state_dict_move(ge, "cpu", emu)
 
 
+@pytest.mark.parametrize("mode", [True, "next_step"])
+def test_emulated_prefetch_survives_a_reset_in_the_middle_of_a_rollout(emu, mode):
+    hc.check_prefetch_reset_mid_rollout(ge, "cpu", emu, mode)
+
+
+def test_emulated_prefetch_state_dict_in_next_step_mode(emu):
+    hc.check_prefetch_state_dict_next_step(ge, "cpu", emu)
+
+
 @pytest.mark.parametrize("env_id,kw", [("TSP-v0", dict(n_nodes=14, n_edges=50, parenting=1)), ("TSP-v0", dict(n_nodes=12, n_edges=30, parenting=2, spatial=True)),
                                        ("MaxIndependentSet-v0", dict(n_nodes=20, n_edges=45, weighted=False)),
                                        ("MaxIndependentSet-v0", dict(n_nodes=36, n_edges=80, weighted=False)),

@@ -615,3 +615,14 @@ def test_prefetch_reproduces_the_engine_without_it(env_id, kw, B, period, mode):
     assert int(a.t["episode"].sum()) > 0 and served > 0
     a.check_device_errors(); b.check_device_errors()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", [True, "next_step"])
+def test_prefetch_survives_a_reset_in_the_middle_of_a_rollout(mode):
+    import host_checks as hc
+    hc.check_prefetch_reset_mid_rollout(_ge(), "cuda", None, mode)
+
+
+def test_prefetch_state_dict_in_next_step_mode():
+    import host_checks as hc
+    hc.check_prefetch_state_dict_next_step(_ge(), "cuda", None)
