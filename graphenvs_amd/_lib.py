@@ -77,7 +77,7 @@ IMAGE_FIELDS = ["x", "edge_index", "edge_attr", "row_ptr", "colw", "scode", "sw6
 SYMBOLS = [
     "ge_abi_version", "ge_get_layout", "ge_create", "ge_destroy", "ge_ragged_table_bytes", "ge_create_ragged", "ge_reset", "ge_step", "ge_step_only",
     "ge_reset_pending", "ge_reset_continue", "ge_inject_state", "ge_mark_restored", "ge_vectorize", "ge_sample_actions", "ge_random_rollout",
-    "ge_timed_rollout", "ge_timed_step_burst", "ge_last_error", "ge_source_hash", "ge_attach_spares",
+    "ge_timed_rollout", "ge_timed_step_burst", "ge_timed_empty_burst", "ge_last_error", "ge_source_hash", "ge_attach_spares",
 ]
 
 
@@ -178,6 +178,9 @@ def bind(lib):
                                      C.POINTER(C.c_double)]
     lib.ge_timed_step_burst.restype = C.c_int
     lib.ge_timed_step_burst.argtypes = [vp, u64, i32, vp, vp, C.POINTER(C.c_double)]
+    if hasattr(lib, "ge_timed_empty_burst"):
+        lib.ge_timed_empty_burst.restype = C.c_int
+        lib.ge_timed_empty_burst.argtypes = [vp, i32, vp, C.POINTER(C.c_double)]
     lib.ge_last_error.restype = C.c_char_p
     lib.ge_last_error.argtypes = []
     lib.ge_source_hash.restype = C.c_char_p
@@ -188,7 +191,7 @@ def bind(lib):
 _lib = None
 
 
-ABI_VERSION = 4  # GE_ABI_VERSION of include/graphenvs.h this host was written against
+ABI_VERSION = 5  # GE_ABI_VERSION of include/graphenvs.h this host was written against
 
 
 def load():

@@ -896,6 +896,24 @@ extern "C" int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k
   return GE_OK;
 }
 
+// the launch floor of the step kernel's shape (bench.py: reported beside the kernel's own duration, never subtracted from it)
+GE_KERNEL ge_k_empty(int) {}
+extern "C" int ge_timed_empty_burst(ge_engine *e, int32_t k, void *stream, double *burst_ms) {
+  if (!e || !burst_ms) return fail(GE_E_BADARG, "null argument");
+  if (!e->have_events) { for (int j = 0; j < 4; j++) if (hipEventCreate(&e->ev[j]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventCreate failed"); e->have_events = true; }
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (e->P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
+  const bool quad = edge_quad(e);
+  (void)hipEventRecord(e->ev[0], st);
+  for (int j = 0; j < k; j++) GE_LAUNCH(ge_k_empty, grid, quad ? GE_EDGE_THREADS : GE_STEP_BLOCK, quad ? ge_edge_lds_bytes(e->P.AW, e->P.W) : step_lds(e), stream, 0);
+  (void)hipEventRecord(e->ev[1], st);
+  if (hipEventSynchronize(e->ev[1]) != hipSuccess) return fail(GE_E_LAUNCH, "hipEventSynchronize failed");
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
+  *burst_ms = ms;
+  return check_launch("empty kernel");
+}
+
 #if !defined(GE_EMU)
 // diagnostic (tools/occupancy.py): resident workgroups per CU the runtime reports for the reset-path kernels
 extern "C" int ge_debug_occupancy(ge_engine *e, int *out4) {

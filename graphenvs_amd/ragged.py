@@ -148,6 +148,13 @@ class RaggedVectorEnv:
         _lib.check(self._L, self._L.ge_random_rollout(self._h, int(policy_seed), int(n_steps), self._actions.data_ptr(), self._stream()),
                    "ge_random_rollout")
 
+    def timed_rollout(self, n_steps, policy_seed=0):
+        """the rollout with a HIP-event pair around the policy, the step kernel and the autoreset launches of every step (profiling)"""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self._L, self._L.ge_timed_rollout(self._h, int(policy_seed), int(n_steps), self._actions.data_ptr(), self._stream(),
+                                                     C.byref(a), C.byref(b), C.byref(c)), "ge_timed_rollout")
+        return dict(step_ms=a.value, reset_ms=b.value, policy_ms=c.value)
+
     def flat_obs(self):
         """utils.vectorize_graph of every slot, one [B_c, obs_len_c] tensor per class (views of one buffer)."""
         lens = [c.num_envs * c.obs_len for c in self.classes]

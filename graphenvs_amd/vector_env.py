@@ -470,6 +470,15 @@ class VectorGraphEnv(_VectorBase):
                                                         self._stream(), C.byref(ms)), "ge_timed_step_burst")
         return ms.value * 1e3 / k
 
+    def launch_floor_us(self, k=5, reps=9):
+        """what an EMPTY launch of the step kernel's shape takes (median of `reps` bursts of k), microseconds"""
+        ms, vals = C.c_double(), []
+        empty = sorted(self.timed_step_burst_raw_ms(0) for _ in range(reps))[reps // 2]
+        for _ in range(reps):
+            _lib.check(self._L, self._L.ge_timed_empty_burst(self._h, int(k), self._stream(), C.byref(ms)), "ge_timed_empty_burst")
+            vals.append((ms.value - empty) * 1e3 / k)
+        return sorted(vals)[reps // 2]
+
     def inject_state(self, links, wcode, x, terminals=None, seeds=None):
         """Parity path: load post-reset states produced elsewhere (links [B,E,2] local ids, wcode [B,E] in
         {3..10}, x [B,n,F], terminals [B,T]).  ``seeds`` [B] (optional): the seed each injected episode is taken to have;

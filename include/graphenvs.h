@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 4
+#define GE_ABI_VERSION 5
 
 /* env ids of graph_envs/__init__.py:9-56 that are on the hot path */
 enum {
@@ -285,6 +285,10 @@ int ge_timed_rollout(ge_engine *e, uint64_t policy_seed, int32_t n_steps, int64_
  * Returns the elapsed milliseconds of the k launches (synchronises; profiling only). */
 int ge_timed_step_burst(ge_engine *e, uint64_t policy_seed, int32_t k, int64_t *actions_scratch, void *stream,
                         double *burst_ms);
+
+/* the launch floor of the step kernel: k back-to-back launches of an EMPTY kernel with the step kernel's grid, block and dynamic
+ * LDS between one pair of hipEvents (synchronises; profiling only: bench.py reports it beside the step kernel's own duration). */
+int ge_timed_empty_burst(ge_engine *e, int32_t k, void *stream, double *burst_ms);
 
 const char *ge_last_error(void);
 
