@@ -285,8 +285,8 @@ static int finish_create(ge_engine *e, ge_engine **out) {
   }
   // ---- feature kernels
   e->feat_fast = any64 ? 1 : 0;  // (spatial TSP: float64 weights do not fit the fast path's LDS)
-  e->feat64_pre_off = ge_align16(f64_body + 8);
-  e->feat_lds = e->feat_fast ? e->feat64_pre_off + (nblk + 2) * 4 + 16 : gen_lds;
+  e->feat64_pre_off = ge_align16(f64_body);  // the item bodies (the queue prefix overlays them), then the tail {item slots, overflow flag}
+  e->feat_lds = e->feat_fast ? e->feat64_pre_off + GE_F64_ITEMS * 4 * 4 + 16 : gen_lds;
   e->gen_lds = gen_lds;
   e->gen_pre_off = P.ldsf.pre;
   if (rg) { e->gen_pre_off = ge_align16(gen_lds); e->gen_lds = e->gen_pre_off + (nblk + 2) * 4; }

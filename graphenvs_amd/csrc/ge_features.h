@@ -1,8 +1,7 @@
 // Structural-feature kernels: the five columns of feature_extraction.py:6-37 for freshly generated slots.
 //   ge_features_generic_env : any n; graph staged in LDS, level-synchronous Brandes, one source at a time.
-//   ge_features64_env       : n <= 64; one LANE per BFS source -- every lane walks its own shortest-path DAG
-//                             with 64-bit set arithmetic (ctz over frontier words), sigma/delta live in LDS
-//                             columns [node][lane], so the 64 sources advance together without barriers.
+//   ge_f64_walk_env / ge_f64_node_env : n <= 64; eight lanes per BFS source, path counts and dependencies pulled level by level
+//                             (no atomics); clustering and pagerank one lane per node, as an item of their own.
 // Both produce float64 results in the reference's operation order where the order is observable, then round to
 // float32 exactly once (sf = torch.tensor(sf)).
 #pragma once
@@ -352,161 +351,312 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
 }
 
 // ------------------------------------------------------------------------------------------------
-// n <= 64 fast path.  LDS carve (bytes): abits 512 | lvl LV*512 | sig 64*66*2 | del 64*65*8 |
-// x,y,sinv,diff,clos 5*512 | scode E (TSP only) | pre.
+// n <= 64 fast path.  A 256-thread workgroup (four waves) works on ITEMS of two kinds:
+//   walk item (one slot): betweenness and closeness.  The 64 BFS sources are dealt to the four waves in two rounds of eight sources
+//     per wave, EIGHT LANES per source (an octet).  Per round and wave: (1) the levels of the eight searches by bit-row arithmetic
+//     -- lane o of an octet holds the adjacency rows of nodes 8o .. 8o+7 in registers, ORs the rows of its nodes of the current
+//     level, and three DPP moves combine the octet -- which also leaves every search's nodes in (level, node) order; (2) path counts
+//     by PULL, level by level: lane o takes the o-th, (o+8)-th ... node of the level, intersects its adjacency row with the level
+//     above and adds the counts of those nodes (plain LDS reads: no atomics, a node's count is written once, by its lane);
+//     (3) dependencies the same way from the deepest level up: S(v) = sum over v's successors w of (1 / sigma(w) + S(w)), in
+//     ascending w; (4) wave 0 adds sigma(v) S(v) to the betweenness of v over the round's 32 sources IN SOURCE ORDER (networkx
+//     adds source after source: the float64 order of that sum is kept).  A wave keeps eight sources in LDS at a time (S 4 KB, counts
+//     1 KB, level sets, order): 28 KB per workgroup where the walk of all 64 sources at once took 52 KB -- five workgroups per CU
+//     instead of three -- and no LDS atomics (ds_add_f64 is one wave-instruction per 8 cycles of a CU's LDS,
+//     tools/micro/valu_issue.hip).
+//   node item (four slots, one per wave, one lane per node): clustering, scipy-order pagerank, degrees.
+// The two kinds write different columns of x and share nothing, so they are independent items of one launch; a launch over c
+// slots has c walk items followed by ceil(c / 4) node items.  Slots deeper than GE_F64_LV levels or with a path count of GE_F64_INV or
+// more go to work_list: the generic kernel recomputes all five columns of such a slot.
 #ifndef GE_F64_LV
-#define GE_F64_LV 12   // BFS levels kept per source; deeper graphs (or sigma > 65535) take the generic path
+#define GE_F64_LV 12   // BFS levels kept per source; deeper graphs take the generic path
 #endif
-#define GE_F64_SS 66   // u16 stride of a sigma row  (33 dwords: odd, spreads banks)
-#define GE_F64_SD 65   // f64 stride of a delta row
-
 #ifndef GE_F64_INV
-#define GE_F64_INV 128  // reciprocals 1/k kept in LDS for the path counts k < GE_F64_INV (larger counts divide)
-#endif
-struct GeF64 { uint64_t *abits, *lvl; uint16_t *sig; double *del, *x, *y, *sinv, *diff, *clos, *inv; uint8_t *scode; };
-
-GE_HOSTDEV int ge_f64_bytes(int E, int tsp, int nblk) {
-  int o = 512 + GE_F64_LV * 512 + 64 * GE_F64_SS * 2 + 64 * GE_F64_SD * 8 + 5 * 512 + GE_F64_INV * 8;
-  o = (o + 15) & ~15;
-  if (tsp) o += (E + 15) & ~15;
-  return o + (nblk + 2) * 4 + 16;
-}
-
-GE_DEV GeF64 ge_carve_f64(int E, int tsp) {
-  unsigned char *s = ge_dyn_smem();
-  GeF64 c;
-  c.abits = (uint64_t *)s; s += 512;
-  c.lvl = (uint64_t *)s; s += GE_F64_LV * 512;
-  c.del = (double *)s; s += 64 * GE_F64_SD * 8;
-  c.x = (double *)s; s += 512; c.y = (double *)s; s += 512; c.sinv = (double *)s; s += 512; c.diff = (double *)s; s += 512; c.clos = (double *)s; s += 512;
-  c.inv = (double *)s; s += GE_F64_INV * 8;
-  c.sig = (uint16_t *)s; s += 64 * GE_F64_SS * 2;
-  c.scode = (uint8_t *)(((uintptr_t)s + 15) & ~(uintptr_t)15);
-  return c;
-}
-// byte offset of the queue prefix (nblk + 1 ints) and the overflow flag inside the dynamic LDS of the n <= 64 feature kernel
-GE_HOSTDEV int ge_f64_pre_off(int E, int tsp, int nblk) { return ge_f64_bytes(E, tsp, nblk) - (nblk + 2) * 4 - 8; }
-
-// 320-thread workgroup.  Waves 0-3 are the walkers: the Brandes walks are chains of LDS round trips, so the 64
-// sources are spread over four waves (16 quads each) on the CU's four SIMDs.  Wave 4 is the node wave (one lane
-// per node): it computes clustering and pagerank WHILE the walkers run their forward pass, then reduces
-// betweenness / closeness and writes the five columns.  Slots that are too deep or whose path counts exceed the
-// 16-bit counters are appended to work_list for the generic kernel.
-#ifndef GE_F64_QL
-#define GE_F64_QL 4  // lanes per BFS source (4 = quad: 16 sources per wave, 4 walker waves; 2 = pair: 32 per wave, 2 waves)
-#endif
-#ifndef GE_F64_K
-#define GE_F64_K 3   // nodes of a level a quad handles per walk iteration (measured on the headline config: 2: 248 us, 3: 242 us, 4: 244 us)
+#define GE_F64_INV 128  // reciprocals 1/k kept in LDS for the path counts k < GE_F64_INV; a slot with a larger count takes the generic path
+                        // (G(64, 192): the largest count of a graph is 25 in the median, 47 at the 99.9th percentile)
 #endif
 #ifndef GE_F64_ABL
-#define GE_F64_ABL 0  // diagnostic ablation bits (tools/f64_phase.py; the results are wrong by construction): 1 forward walk, 2 backward walk, 4 pagerank
-                      // iterations, 8 clustering, 16 betweenness reduction; 0 when shipped
+#define GE_F64_ABL 0  // diagnostic ablation bits (tools/f64_phase.py; the results are wrong by construction): 1 forward pull, 2 backward pull, 4 pagerank
+                      // iterations, 8 clustering, 16 betweenness reduction, 32 level search; 0 when shipped
 #endif
-#define GE_F64_WALKERS (64 * GE_F64_QL)
-#define GE_F64_THREADS (GE_F64_WALKERS + 64)
-#define GE_F64_SLICE (64 / GE_F64_QL)  // nodes per lane slice
-#if GE_F64_SLICE > 32
-typedef uint64_t ge_slice_t;  // one lane per source: the lane serves every target itself
-#define GE_SLICE_CTZ(x) ge_ctz64(x)
+#ifndef GE_F64_U
+#define GE_F64_U 2    // entries of a predecessor / successor set a pull reads per trip, their LDS reads in flight together (headline loop, feature
+                      // kernel alone: 1 -> 172 us, 2 -> 151, 3 -> 161, 4 -> 172, 6 -> 197: the kernel is bound by vector issue, and entries
+                      // that do not exist cost their instructions)
+#endif
+#define GE_F64_THREADS 256
+#define GE_F64_WAVES 4
+#define GE_F64_SB 8                      // sources of a wave's sub-batch: eight lanes each
+#define GE_F64_LST 16                    // level starts kept per source (GE_F64_LV + 1 <= GE_F64_LST)
+#define GE_F64_ITEMS 16                  // items a workgroup looks up per queue-prefix rebuild
+static_assert(GE_F64_LV + 1 <= GE_F64_LST, "level starts");
+// per-wave area of a walk item
+// (rows of S and sigma carry a 65th entry that stays zero: the pulls read GE_F64_U entries of a set per trip and point the ones that
+// do not exist at it -- coeff = inv[0] + 0.0 = +0.0 leaves a sum as it is)
+#define GE_F64_SS 65                                              // row stride of S (float64)
+#define GE_F64_SG 66                                              // row stride of sigma (u16; whole dwords)
+#define GE_F64_A_S 0                                              // double  S[8][65]
+#define GE_F64_A_SIG (GE_F64_A_S + GE_F64_SB * GE_F64_SS * 8)     // u16 sigma[8][66]
+#define GE_F64_A_LVL (GE_F64_A_SIG + GE_F64_SB * GE_F64_SG * 2)   // u64 lvl[GE_F64_LV][8]
+#define GE_F64_A_ORD (GE_F64_A_LVL + GE_F64_LV * GE_F64_SB * 8)   // u8 ord[8][64]: the nodes of a search in (level, node) order
+#define GE_F64_A_LST (GE_F64_A_ORD + GE_F64_SB * 64)              // u8 lst[8][GE_F64_LST]: where level d starts in ord
+#define GE_F64_A_BYTES (GE_F64_A_LST + GE_F64_SB * GE_F64_LST)
+// walk item: abits 512 | inv | clos 512 | four wave areas
+#define GE_F64_W_INV 512
+#define GE_F64_W_CLOS (GE_F64_W_INV + GE_F64_INV * 8)
+#define GE_F64_W_AREA (GE_F64_W_CLOS + 512)
+#define GE_F64_W_BYTES (GE_F64_W_AREA + GE_F64_WAVES * GE_F64_A_BYTES)
+
+// node item, per wave: abits 512 | x, y, sinv, diff 4 x 512 | scode E (TSP only: weighted pagerank)
+GE_HOSTDEV int ge_f64_node_wave_bytes(int E, int tsp) { return 512 + 4 * 512 + (tsp ? ((E + 15) & ~15) : 0); }
+// bytes of the item bodies (the queue prefix of a launch overlays them: nblk + 2 ints) = offset of the tail {items[64], flag}
+GE_HOSTDEV int ge_f64_pre_off(int E, int tsp, int nblk) {
+  int o = GE_F64_W_BYTES;
+  const int nd = GE_F64_WAVES * ge_f64_node_wave_bytes(E, tsp), pf = (nblk + 2) * 4;
+  if (nd > o) o = nd;
+  if (pf > o) o = pf;
+  return (o + 15) & ~15;
+}
+GE_HOSTDEV int ge_f64_bytes(int E, int tsp, int nblk) { return ge_f64_pre_off(E, tsp, nblk) + GE_F64_ITEMS * 4 * 4 + 16; }
+
+// index of the lowest set bit of b, GE_F64_U times over (b loses them); a set that runs out gives `none` (the row's zero entry)
+template <int BASE>
+GE_DEV void ge_f64_next_bits(uint32_t &b, int (&idx)[GE_F64_U]) {
+#pragma unroll
+  for (int j = 0; j < GE_F64_U; j++) {
+#ifdef GE_EMU
+    idx[j] = b ? BASE + __builtin_ctz(b) : 64;
 #else
-typedef uint32_t ge_slice_t;
-#define GE_SLICE_CTZ(x) ((int)__builtin_ctz(x))
+    uint32_t z;  // v_ffbl_b32 gives 0xffffffff for an empty set: the minimum turns that into the zero entry's index
+    asm("v_ffbl_b32 %0, %1" : "=v"(z) : "v"(b));
+    idx[j] = (int)((z < (uint32_t)(64 - BASE) ? z : (uint32_t)(64 - BASE)) + (uint32_t)BASE);
 #endif
-GE_DEV void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32_t *work_count, int32_t *work_list, int env_global) {
+    b &= b - 1u;
+  }
+}
+// sum of the path counts row[i] over the set bits i of the 64-bit set p (integers: exact in any order)
+GE_DEV uint32_t ge_f64_sum_counts(const uint16_t *row, uint64_t p) {
+  uint32_t acc = 0u;
+  for (uint32_t b = (uint32_t)p; b;) {
+    int ix[GE_F64_U]; uint32_t r[GE_F64_U];
+    ge_f64_next_bits<0>(b, ix);
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) r[j] = row[ix[j]];
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) acc += r[j];
+  }
+  for (uint32_t b = (uint32_t)(p >> 32); b;) {
+    int ix[GE_F64_U]; uint32_t r[GE_F64_U];
+    ge_f64_next_bits<32>(b, ix);
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) r[j] = row[ix[j]];
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) acc += r[j];
+  }
+  return acc;
+}
+// sum over the set bits w of sc, ascending, of coeff(w) = 1 / sigma(w) + S(w)
+#ifndef GE_F64_COEFF
+#define GE_F64_COEFF 0  // diagnostic variant (not shipped): the float64 buffer holds coeff(w) = 1 / sigma(w) + S(w) instead of S(w) -- one LDS read per
+                        // successor instead of three -- and the reduction recovers S as coeff - 1 / sigma, which is S up to the rounding
+                        // of that one addition (exact for a node without successors)
+#endif
+template <int BASE>
+GE_DEV double ge_f64_sum_coeff_half(const uint16_t *sigrow, const double *Srow, const double *inv, uint32_t b, double acc) {
+#if GE_F64_COEFF
+  while (b) {
+    int ix[GE_F64_U]; double sw[GE_F64_U];
+    ge_f64_next_bits<BASE>(b, ix);
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) sw[j] = Srow[ix[j]];
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) acc += sw[j];
+  }
+  return acc;
+#endif
+  while (b) {
+    int ix[GE_F64_U]; uint32_t sg[GE_F64_U]; double sw[GE_F64_U], iv[GE_F64_U];
+    ge_f64_next_bits<BASE>(b, ix);
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) { sg[j] = sigrow[ix[j]]; sw[j] = Srow[ix[j]]; }
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) iv[j] = inv[sg[j]];  // (every count of a slot that is pulled is below GE_F64_INV)
+#pragma unroll
+    for (int j = 0; j < GE_F64_U; j++) acc += iv[j] + sw[j];
+  }
+  return acc;
+}
+
+// Betweenness and closeness of slot `env` (one workgroup, four waves).
+GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *work_count, int32_t *work_list, int env_global) {
   const int tid = ge_tid_fresh();
-  const bool node_wave = tid >= GE_F64_WALKERS;
-  const int lane = tid - GE_F64_WALKERS;  // node index inside the node wave
+  const int lane = tid & (GE_WAVE - 1), wv = tid >> 6;
+  const int n = P.n, F = P.F;
+  const ge_buffers &G = P.buf;
+  const int64_t nbase = (int64_t)env * n;
+  unsigned char *const sm = ge_dyn_smem();
+  uint64_t *const abits = (uint64_t *)sm;
+  double *const inv = (double *)(sm + GE_F64_W_INV), *const clos = (double *)(sm + GE_F64_W_CLOS);
+  unsigned char *const area = sm + GE_F64_W_AREA + wv * GE_F64_A_BYTES;
+  double *const S = (double *)(area + GE_F64_A_S);
+  uint16_t *const sig = (uint16_t *)(area + GE_F64_A_SIG);
+  uint64_t *const lvl = (uint64_t *)(area + GE_F64_A_LVL);
+  uint8_t *const ord = (uint8_t *)(area + GE_F64_A_ORD), *const lst = (uint8_t *)(area + GE_F64_A_LST);
+  GE_STAMP(11);
+  if (wv == 0) abits[lane] = lane < n ? G.adj_bits[nbase + lane] : 0ull;
+  if (tid == 0) *ovf_flag = 0;
+  for (int i = tid; i < GE_F64_INV; i += GE_F64_THREADS) inv[i] = i > 0 ? 1.0 / (double)i : 0.0;  // correctly rounded reciprocals; [0]: the zero entry of a row
+  ge_sync();
+  GE_STAMP(12);
+  const int sl = lane >> 3, o = lane & 7;  // source of the sub-batch, lane of its octet
+  // the adjacency rows of this lane's eight nodes (the same in both rounds)
+  uint32_t rlo[8], rhi[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { const uint64_t r = abits[8 * o + j]; rlo[j] = (uint32_t)r; rhi[j] = (uint32_t)(r >> 32); }
+  const uint64_t below_o = (1ull << (8 * o)) - 1ull;  // the nodes of the octet lanes below this one
+  uint16_t *const sigrow = sig + sl * GE_F64_SG; double *const Srow = S + sl * GE_F64_SS;
+  uint8_t *const ordrow = ord + sl * 64, *const lstrow = lst + sl * GE_F64_LST;
+  double bc = 0.0;  // wave 0: betweenness of node `lane`, sources added in order
+  bool ovf = false;
+  for (int r = 0; r < 2; r++) {
+    const int s = 32 * r + GE_F64_SB * wv + sl;  // this octet's source
+    const bool src = s < n;
+    // ---- (1) levels: lvl[d][sl] = the nodes at distance d from s; ord / lst = the same nodes in (level, node) order
+    uint64_t vis = src ? (1ull << s) : 0ull, cur = vis;
+    int D = 0, reach = 1, start = src ? 1 : 0, Dw = 0; int64_t tot = 0;
+    if (o == 0) { lvl[sl] = cur; lstrow[0] = 0; lstrow[1] = (uint8_t)start; if (src) ordrow[0] = (uint8_t)s; }
+    for (int d = 1; !(GE_F64_ABL & 32); d++) {
+      const uint32_t cb = (uint32_t)(cur >> (8 * o)) & 0xffu;  // which of my eight nodes are in the current level
+      uint32_t nlo = 0u, nhi = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const uint32_t m = 0u - ((cb >> j) & 1u); nlo |= m & rlo[j]; nhi |= m & rhi[j]; }
+      nlo = ge_oct_or32(nlo); nhi = ge_oct_or32(nhi);
+      const uint64_t nw = (((uint64_t)nhi << 32) | (uint64_t)nlo) & ~vis;  // (the same in the eight lanes)
+      if (!ge_ballot(nw != 0ull)) break;  // no search of this wave found a new node
+      Dw = d;
+      vis |= nw; cur = nw;
+      if (nw) {
+        const int cnt = ge_popc64(nw);
+        D = d; reach += cnt; tot += (int64_t)d * cnt;
+        if (d < GE_F64_LV) {
+          if (o == 0) lvl[d * GE_F64_SB + sl] = nw;
+          int pos = start + ge_popc64(nw & below_o);
+          for (uint32_t nb = (uint32_t)(nw >> (8 * o)) & 0xffu; nb; nb &= nb - 1u) ordrow[pos++] = (uint8_t)(8 * o + __builtin_ctz(nb));
+        } else ovf = true;
+        start += cnt;
+      }
+      if (o == 0 && d + 1 < GE_F64_LST) lstrow[d + 1] = (uint8_t)start;  // (a search that ended earlier: an empty level)
+    }
+    if (o == 0 && src) {  // closeness_centrality, wf_improved
+      double cl = 0.0;
+      if (tot > 0 && n > 1) { cl = ((double)reach - 1.0) / (double)tot; cl *= ((double)reach - 1.0) / (double)(n - 1); }
+      clos[s] = cl;
+    }
+    if (r > 0) ge_sync();  // wave 0 has added the previous round's dependencies: S and sigma may be rewritten
+    // ---- zero the round's counts and dependency sums (a node no search reaches keeps 0 x 0.0)
+    for (int i = lane; i < GE_F64_SB * GE_F64_SG / 2; i += GE_WAVE) ((uint32_t *)sig)[i] = 0u;
+    for (int i = lane; i < GE_F64_SB * GE_F64_SS; i += GE_WAVE) S[i] = 0.0;
+    ge_wave_sync();
+    if (o == 0 && src) sigrow[s] = 1;
+    const bool deep = ge_ballot(ovf) != 0ull;  // the slot goes to the generic kernel: skip the pulls (their level arrays would overrun)
+    ge_wave_sync();
+    // ---- (2) path counts: sigma(v) = sum of sigma(u) over v's neighbours u in the level above
+    for (int d = 1; d <= Dw && !deep && !(GE_F64_ABL & 1); d++) {
+      const int lo = lstrow[d], hi = lstrow[d + 1];
+      const uint64_t prev = lvl[(d - 1) * GE_F64_SB + sl];
+      for (int k = lo + o; ge_ballot(k < hi) != 0ull; k += 8) {
+        if (k < hi) {
+          const int v = ordrow[k];
+          const uint64_t p = abits[v] & prev;
+          const uint32_t acc = ge_f64_sum_counts(sigrow, p);
+          sigrow[v] = (uint16_t)acc;      // (<= 64 x (GE_F64_INV - 1))
+          if (acc >= (uint32_t)GE_F64_INV) ovf = true;  // no reciprocal in the table: the generic kernel takes the slot
+        }
+      }
+      ge_wave_sync();
+    }
+    // ---- (3) dependencies, deepest level first: S(v) = sum over v's neighbours w one level down of coeff(w),
+    // coeff(w) = (1 + delta(w)) / sigma(w) with delta(w) = sigma(w) S(w), i.e. 1 / sigma(w) + S(w): the reciprocal of the (small,
+    // integer) path count comes from the LDS table, one float64 add instead of a multiply, an add and a division
+    const bool deep2 = ge_ballot(ovf) != 0ull;
+#if GE_F64_COEFF
+    if (!deep2) for (int i = lane; i < GE_F64_SB * 64; i += GE_WAVE) { const int a = (i >> 6) * GE_F64_SS + (i & 63), g = (i >> 6) * GE_F64_SG + (i & 63); S[a] = inv[sig[g]]; }
+    ge_wave_sync();
+#endif
+    for (int d = Dw - 1; d >= 1 && !deep2 && !(GE_F64_ABL & 2); d--) {
+      const bool mine = d < D;  // (level D of this search has no successors: S stays 0)
+      const int lo = lstrow[d], hi = mine ? lstrow[d + 1] : lo;
+      const uint64_t next = lvl[(d + 1) * GE_F64_SB + sl];
+      for (int k = lo + o; ge_ballot(k < hi) != 0ull; k += 8) {
+        if (k < hi) {
+          const int v = ordrow[k];
+          const uint64_t sc = abits[v] & next;
+          double acc = ge_f64_sum_coeff_half<0>(sigrow, Srow, inv, (uint32_t)sc, 0.0);
+          acc = ge_f64_sum_coeff_half<32>(sigrow, Srow, inv, (uint32_t)(sc >> 32), acc);
+#if GE_F64_COEFF
+          acc += inv[sigrow[v]];
+#endif
+          Srow[v] = acc;
+        }
+      }
+      ge_wave_sync();
+    }
+    if (ovf) *ovf_flag = 1;
+    ge_sync();  // every wave's S and sigma of this round are complete
+    // ---- (4) betweenness[v] += delta_s(v) = sigma_s(v) S_s(v), s != v, source after source (a node a search did not reach, the
+    // source itself and a source that does not exist add +0.0)
+    if (wv == 0 && !(GE_F64_ABL & 16)) {
+#pragma unroll 1
+      for (int w = 0; w < GE_F64_WAVES; w++) {
+        const unsigned char *const aw = sm + GE_F64_W_AREA + w * GE_F64_A_BYTES;
+        const uint16_t *const sgw = (const uint16_t *)(aw + GE_F64_A_SIG) + lane; const double *const Sw = (const double *)(aw + GE_F64_A_S) + lane;
+        uint32_t sg[GE_F64_SB]; double sv[GE_F64_SB];
+#pragma unroll
+        for (int k = 0; k < GE_F64_SB; k++) { sg[k] = sgw[GE_F64_SG * k]; sv[k] = Sw[GE_F64_SS * k]; }
+#if GE_F64_COEFF
+#pragma unroll
+        for (int k = 0; k < GE_F64_SB; k++) sv[k] -= inv[sg[k] < GE_F64_INV ? sg[k] : 0u];
+#endif
+#pragma unroll
+        for (int k = 0; k < GE_F64_SB; k++) bc += (32 * r + GE_F64_SB * w + k != lane) ? (double)sg[k] * sv[k] : 0.0;
+      }
+    }
+  }
+  GE_STAMP(14);
+  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel (it recomputes all five columns)
+    if (tid == 0) { int k = atomicAdd(&work_count[0], 1); work_list[k] = env_global; }
+    ge_sync();
+    return;
+  }
+  if (wv == 0 && lane < n) {
+    if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
+    float *xr = G.x + (nbase + lane) * F + P.nflag;
+    xr[1] = (float)bc; xr[2] = (float)clos[lane];
+  }
+  ge_sync();  // (the next item rewrites the LDS)
+  GE_STAMP(17);
+}
+
+// Clustering, pagerank and degrees of slot `env`: ONE wave, a lane per node, on the wave's own LDS area (no workgroup barrier).
+GE_DEV void ge_f64_node_env(const GeParams &P, int env, unsigned char *area, int lane) {
   const int n = P.n, E = P.E, F = P.F, t = P.env_type;
   const ge_buffers &G = P.buf;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
   const bool prw = (t == GE_TSP);
-  GeF64 c = ge_carve_f64(E, prw);
-  const bool live = node_wave && lane < n;
-  GE_STAMP(11);
+  uint64_t *const abits = (uint64_t *)area;
+  double *const cx = (double *)(area + 512), *const cy = cx + 64, *const csinv = cx + 128, *const cdiff = cx + 192;
+  uint8_t *const scode = area + 512 + 4 * 512;
+  const bool live = lane < n;
   const uint64_t adj = live ? G.adj_bits[nbase + lane] : 0ull;
   const int deg = ge_popc64(adj);
-  if (node_wave) c.abits[lane] = adj;
-  if (tid == 0) *ovf_flag = 0;
-  for (int i = tid; i < 64 * GE_F64_SS / 2; i += GE_F64_THREADS) ((uint32_t *)c.sig)[i] = 0u;
-  for (int i = tid; i < 64 * GE_F64_SD; i += GE_F64_THREADS) c.del[i] = 0.0;
-  if (prw) for (int i = tid; i < E; i += GE_F64_THREADS) c.scode[i] = G.scode[ebase + i];
-  for (int i = tid; i < GE_F64_INV; i += GE_F64_THREADS) c.inv[i] = 1.0 / (double)(i > 0 ? i : 1);  // correctly rounded reciprocals
-  ge_sync();
-
-  GE_STAMP(12);
-  // ---- Brandes, lane = source.  Forward: BFS + path counts, pushing sigma along DAG edges.
-  // Four lanes (a quad) per source, 16 sources per wave: the quad keeps identical copies of the walk state and
-  // splits the pushes of a node -- lane q takes the q-th, (q+4)-th, ... target -- so a node's DAG edges are
-  // served in parallel while the per-source order of the float64 delta sums stays fixed.
-  const int s = (tid >> 6) * (64 / GE_F64_QL) + ((tid & 63) / GE_F64_QL);
-  const int q = tid & (GE_F64_QL - 1);
-  const bool walker = !node_wave && s < n;
-  // push targets of this lane: node (SLICE q + b), b = bit inside the slice.  The sigma counters are half-words, two to a dword;
-  // a row is GE_F64_SS (even) half-words, so the dword of (node, s) is row * SS/2 + (s >> 1) and the half inside it depends on s
-  // alone: one multiply-add per push instead of rebuilding the index
-  static_assert(GE_F64_SS % 2 == 0, "sigma rows must be whole dwords");
-  uint32_t *const sig_mine = (uint32_t *)c.sig + (GE_F64_SLICE * q) * (GE_F64_SS / 2) + (s >> 1);
-  const int sig_sh = 16 * (s & 1);
-  double *const del_mine = c.del + (GE_F64_SLICE * q) * GE_F64_SD + s;
-  bool ovf = false;
-  int D = 0, reach = 1; int64_t tot = 0;
-  GE_STAMP_T0(24);
-  static_assert(GE_F64_QL == 4, "the walk keeps the visited / next-level sets as 16-bit slices, one per lane of a quad");
-  const uint16_t *const adj_mine = (const uint16_t *)c.abits + q;  // this lane's 16 columns of an adjacency row: adj_mine[4 u]
-  if (walker && !(GE_F64_ABL & 1)) {
-    // the lane only ever pushes to the nodes of its own slice, so it keeps just that slice of the visited set and of the level being
-    // discovered (one 32-bit operation where the whole sets took two); the quad assembles the whole next level once per level
-    uint64_t cur = 1ull << s;
-    uint32_t vis16 = (uint32_t)((1ull << s) >> (16 * q)) & 0xffffu, nxt16 = 0u;
-    if (q == 0) c.sig[s * GE_F64_SS + s] = 1;
-    for (;;) {
-      if (cur == 0) {
-        const uint64_t nxt = ge_quad_gather16(nxt16);
-        if (!nxt) break;
-        vis16 |= nxt16; D++;
-        if (D < GE_F64_LV) { if (q == 0) c.lvl[D * 64 + s] = nxt; } else ovf = true;
-        const int cnt = ge_popc64(nxt);
-        reach += cnt; tot += (int64_t)D * cnt;
-        cur = nxt; nxt16 = 0u;
-      }
-      ge_quad_sync();  // the quad's pushes of the previous nodes are in LDS before these nodes are read
-      // GE_F64_K nodes of the current level per iteration: their counts are final, their pushes are commutative adds, and the K
-      // reads / push streams are independent of each other (the fixed cost of an iteration is shared, the LDS round trips overlap)
-      int u[GE_F64_K]; bool has[GE_F64_K];
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) { has[k] = cur != 0; u[k] = has[k] ? ge_ctz64(cur) : u[0]; cur &= cur - 1; }
-      uint32_t su[GE_F64_K], ab[GE_F64_K];
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) { su[k] = c.sig[u[k] * GE_F64_SS + s]; ab[k] = adj_mine[4 * u[k]]; }
-      uint32_t any_su = 0; ge_slice_t mine[GE_F64_K], any_mine = 0;
-      const uint32_t open16 = ~vis16;
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) {
-        any_su |= su[k];
-        // lane q of the quad serves the targets in nodes [16q, 16q+16): a 16-bit slice per node, 32-bit bit tricks
-        mine[k] = has[k] ? (ab[k] & open16) : 0u; any_mine |= mine[k];
-        su[k] <<= sig_sh;
-      }
-      nxt16 |= any_mine;
-      if (any_su > 1023u) ovf = true;            // 64 parents x 1023 still fit the 16-bit counters
-      while (any_mine) {
-        any_mine = 0;
-#pragma unroll
-        for (int k = 0; k < GE_F64_K; k++) {
-          if (mine[k]) {  // sigma[v] += sigma[u]: one ds_add_u32 on the half-word's dword, nothing to wait for
-            ge_lds_add_u32(sig_mine + GE_SLICE_CTZ(mine[k]) * (GE_F64_SS / 2), su[k]); mine[k] &= mine[k] - 1;
-          }
-          any_mine |= mine[k];
-        }
-      }
-    }
-  }
+  abits[lane] = adj;
+  if (prw) for (int i = lane; i < E; i += GE_WAVE) scode[i] = G.scode[ebase + i];
+  ge_wave_sync();
   double clus = 0.0, x = 0.0;
-  if (node_wave) {  // concurrent with the walkers' forward pass
   // clustering (directed formula on the symmetric graph)
   if (live && !(GE_F64_ABL & 8)) {
     int64_t common = 0;
-    for (uint64_t r = adj; r; r &= r - 1) common += ge_popc64(adj & c.abits[ge_ctz64(r)]);
+    for (uint64_t r = adj; r; r &= r - 1) common += ge_popc64(adj & abits[ge_ctz64(r)]);
     const int64_t t8 = 8 * common, dt = 2 * (int64_t)deg, db = deg;
     clus = (t8 == 0) ? 0.0 : (double)t8 / (double)((dt * (dt - 1) - 2 * db) * 2);
   }
@@ -514,13 +664,13 @@ GE_DEV void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32_t
   int rp = 0;  // row start in ascending-neighbour order = exclusive scan of degrees
   if (prw) { int incl = ge_wave_incl_scan(deg, lane); rp = incl - deg; }
   double S = 0.0;
-  { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) S += (prw ? ge_wlut(c.scode[rp + k]) : 1.0) * 1.0; }
+  { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) S += (prw ? ge_wlut(scode[rp + k]) : 1.0) * 1.0; }
   const double sinv = (S != 0.0) ? 1.0 / S : 0.0;
   const double pinit = 1.0 / (double)n;
   const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
   const uint64_t dangling = ge_ballot(live && deg == 0);
   x = pinit;
-  c.sinv[lane] = sinv;
+  csinv[lane] = sinv;
   // the 16 smallest neighbours as byte indices in four registers: the pull of an iteration becomes 16 unrolled (predicated) LDS
   // reads and adds in ascending-neighbour order instead of a ctz / clear-lowest-bit loop of max-degree trips; `rest` = what is left
   // of a row with more than 16 neighbours
@@ -528,118 +678,33 @@ GE_DEV void ge_features64_env(const GeParams &P, int env, int *ovf_flag, int32_t
   { int k = 0; for (; rest && k < 16; rest &= rest - 1, k++) nb4[k >> 2] |= (uint32_t)ge_ctz64(rest) << (8 * (k & 3)); }
   bool conv = false;
   for (int it = 0; it < ((GE_F64_ABL & 4) ? 1 : 100) && !conv; it++) {
-    c.x[lane] = x; c.y[lane] = sinv * x;  // unweighted: data'[j->i] * x[j] is the same product for every i
+    cx[lane] = x; cy[lane] = sinv * x;  // unweighted: data'[j->i] * x[j] is the same product for every i
     ge_wave_sync();
     double dsum = 0.0;
-    { bool first = true; for (uint64_t r = dangling; r; r &= r - 1) { double xv = c.x[ge_ctz64(r)]; dsum = first ? xv : dsum + xv; first = false; } }
+    { bool first = true; for (uint64_t r = dangling; r; r &= r - 1) { double xv = cx[ge_ctz64(r)]; dsum = first ? xv : dsum + xv; first = false; } }
     double xn = 0.0;
     if (live) {
       double acc = 0.0;
-      if (prw) { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) { const int j = ge_ctz64(r); acc += (c.sinv[j] * ge_wlut(c.scode[rp + k])) * c.x[j]; } }
+      if (prw) { int k = 0; for (uint64_t r = adj; r; r &= r - 1, k++) { const int j = ge_ctz64(r); acc += (csinv[j] * ge_wlut(scode[rp + k])) * cx[j]; } }
       else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) { const double yv = c.y[(nb4[k >> 2] >> (8 * (k & 3))) & 63u]; acc += (k < deg) ? yv : 0.0; }  // x + 0.0 == x
-        for (uint64_t r = rest; r; r &= r - 1) acc += c.y[ge_ctz64(r)];
+        for (int k = 0; k < 16; k++) { const double yv = cy[(nb4[k >> 2] >> (8 * (k & 3))) & 63u]; acc += (k < deg) ? yv : 0.0; }  // x + 0.0 == x
+        for (uint64_t r = rest; r; r &= r - 1) acc += cy[ge_ctz64(r)];
       }
       xn = alpha * (acc + dsum * pinit) + oma * pinit;
     }
-    c.diff[lane] = live ? __builtin_fabs(xn - x) : 0.0;
+    cdiff[lane] = live ? __builtin_fabs(xn - x) : 0.0;
     ge_wave_sync();
-    const double err = ge_pw<0>(c.diff, n, lane);
+    const double err = ge_pw<0>(cdiff, n, lane);
     x = xn;
     ge_wave_sync();
     if (err < (double)n * tol) conv = true;
   }
-  }
-  // No barrier between the passes: the backward pass only touches the lane's own source columns.  A slot that
-  // overflowed is discarded as a whole after the last barrier (the generic kernel recomputes it).
-  if (ovf) *ovf_flag = 1;
-  GE_STAMP(13);
-  GE_STAMP_T0(25);
-  // Backward: dependencies, deepest level first; delta[v] += sigma[v] * (1 + delta[w]) / sigma[w]
-  if (walker && !ovf && !(GE_F64_ABL & 2)) {
-    int d = D;
-    uint64_t cur = d >= 1 ? c.lvl[d * 64 + s] : 0ull;
-    uint64_t prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s);
-    uint32_t prev16 = (uint32_t)(prev >> (16 * q)) & 0xffffu;  // this lane's slice of the level above
-    while (d >= 1) {
-      if (cur == 0) {
-        d--;
-        if (d >= 1) { cur = c.lvl[d * 64 + s]; prev = d >= 2 ? c.lvl[(d - 1) * 64 + s] : (1ull << s); prev16 = (uint32_t)(prev >> (16 * q)) & 0xffffu; }
-        continue;
-      }
-      ge_quad_sync();
-      // GE_F64_K nodes of the level per iteration (independent division chains overlap).  del[w] holds S(w) = sum of
-      // coeff over w's DAG successors (deeper level, finished); delta(w) = sigma(w) * S(w) and coeff(w) =
-      // (1 + delta(w)) / sigma(w) is pushed to w's predecessors.  S stays in del[]: the betweenness reduction
-      // multiplies by sigma again, so nothing is rewritten here.
-      int w[GE_F64_K]; bool has[GE_F64_K];
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) { has[k] = cur != 0; w[k] = has[k] ? ge_ctz64(cur) : w[0]; cur &= cur - 1; }
-      uint32_t sg[GE_F64_K], ab[GE_F64_K]; double S[GE_F64_K], rs[GE_F64_K];
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) { sg[k] = c.sig[w[k] * GE_F64_SS + s]; S[k] = c.del[w[k] * GE_F64_SD + s]; ab[k] = adj_mine[4 * w[k]]; }
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) rs[k] = c.inv[sg[k] < GE_F64_INV ? sg[k] : 0u];
-      double coeff[GE_F64_K]; ge_slice_t mine[GE_F64_K], any_mine = 0;
-#pragma unroll
-      for (int k = 0; k < GE_F64_K; k++) {
-        // coeff(w) = (1 + delta(w)) / sigma(w) with delta(w) = sigma(w) S(w), i.e. 1 / sigma(w) + S(w): the reciprocal of the
-        // (small, integer) path count comes from the LDS table, one float64 add instead of a multiply, an add and a division
-        coeff[k] = (sg[k] < GE_F64_INV ? rs[k] : 1.0 / (double)sg[k]) + S[k];
-        // lane q serves the predecessors in nodes [16q, 16q+16); a node's accumulator is always updated by the same lane, in the
-        // same interleaving of the K push streams, iteration after iteration: the float64 sum order is fixed
-        mine[k] = has[k] ? (ab[k] & prev16) : 0u; any_mine |= mine[k];
-      }
-      while (any_mine) {
-        any_mine = 0;
-#pragma unroll
-        for (int k = 0; k < GE_F64_K; k++) {
-          if (mine[k]) { ge_lds_add_f64(del_mine + GE_SLICE_CTZ(mine[k]) * GE_F64_SD, coeff[k]); mine[k] &= mine[k] - 1; }  // ds_add_f64
-          any_mine |= mine[k];
-        }
-      }
-    }
-  }
-  GE_STAMP_T0(26);
-  // closeness (wf_improved) of source s, handed to the node-per-lane phase through LDS
-  if (walker && q == 0) {
-    double cl = 0.0;
-    if (tot > 0 && n > 1) { cl = ((double)reach - 1.0) / (double)tot; cl *= ((double)reach - 1.0) / (double)(n - 1); }
-    c.clos[s] = cl;
-  }
-  ge_sync();
-  GE_STAMP(14);
-  if (*ovf_flag) {  // uniform: hand the slot to the generic kernel
-    if (tid == 0) { int k = atomicAdd(&work_count[0], 1); work_list[k] = env_global; }
-    ge_sync();
-    return;
-  }
-  if (node_wave) {  // betweenness / closeness reduction and the write, one lane per node
-  // betweenness[w] = sum over sources in node order, w itself excluded; then the 1/((n-1)(n-2)) rescale
-  double bc = 0.0;
-  if (live && !(GE_F64_ABL & 16)) {
-    // delta = sigma * S, added in source order.  Eight sources per trip with their sixteen LDS reads in flight (the additions stay a
-    // chain, in order); the node's own column and the columns of sources that do not exist (zero, never written) add +0.0.
-#pragma unroll 1
-    for (int s0 = 0; s0 < 64; s0 += 8) {
-      uint32_t sg[8]; double sv[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { sg[k] = c.sig[lane * GE_F64_SS + s0 + k]; sv[k] = c.del[lane * GE_F64_SD + s0 + k]; }
-#pragma unroll
-      for (int k = 0; k < 8; k++) bc += (s0 + k != lane) ? (double)sg[k] * sv[k] : 0.0;
-    }
-    if (n > 2) bc *= 1.0 / (double)((int64_t)(n - 1) * (int64_t)(n - 2));
-  }
-  const double clos = live ? c.clos[lane] : 0.0;
-  GE_STAMP(16);
   if (live) {
     float *xr = G.x + (nbase + lane) * F + P.nflag;
-    xr[0] = (float)(2.0 * (double)deg); xr[1] = (float)bc; xr[2] = (float)clos; xr[3] = (float)x; xr[4] = (float)clus;
+    xr[0] = (float)(2.0 * (double)deg); xr[3] = (float)x; xr[4] = (float)clus;
   }
-  }
-  ge_sync();
-  GE_STAMP(17);
+  ge_wave_sync();
 }
 
 
@@ -707,31 +772,76 @@ GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, GeRun run) {
   }
 }
 
-// n <= 64 fast path over every slot / the queue.  Multi-class engine: a slot of a class with n > 64 goes straight to work_list.
+// n <= 64 fast path over every slot / the queue: walk items [0, count), then node items (four slots each).  Multi-class engine: a
+// slot of a class with n > 64 goes straight to work_list.  A workgroup takes the items bid, bid + grid, ...; in queue mode it looks
+// up the slots of GE_F64_ITEMS of them at a time (the queue prefix overlays the item bodies in LDS and is rebuilt per chunk).
+#ifndef GE_F64_WPS
+#define GE_F64_WPS 5  // waves per SIMD the register allocation of the n <= 64 feature kernel is held to (0: the compiler's choice)
+#endif
+#if GE_F64_WPS > 0
+#define GE_F64_KERNEL GE_KERNEL_LB(GE_F64_THREADS, GE_F64_WPS)
+#else
+#define GE_F64_KERNEL GE_KERNEL
+#endif
 template <bool RAGGED>
-GE_KERNEL ge_k_features64(GeParams P, GeRagged R, GeRun run, int pre_off) {
+GE_F64_KERNEL ge_k_features64(GeParams P, GeRagged R, GeRun run, int tail_off) {
   const int nblk = (P.B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK;
-  int *pre = (int *)(ge_dyn_smem() + pre_off);
+  int *const pre = (int *)ge_dyn_smem();
+  int *const items = (int *)(ge_dyn_smem() + tail_off);  // [GE_F64_ITEMS][4] slots (walk item: the first; -1 = none)
+  int *const ovf_flag = items + GE_F64_ITEMS * 4;
   const bool queue = run.items == GE_ITEMS_QUEUE;
   int count = P.B;
-  if (queue) {  // the prefix scan is one wave wide
-    if (ge_tid() < GE_WAVE) ge_queue_prefix_wave(P, pre, ge_tid());
-    ge_sync();
-    count = pre[nblk];
-  }
-  for (int q = ge_bid(); q < count; q += ge_gdim()) {
-    const int env = queue ? ge_queue_slot(P, pre, q) : q;
-    if (queue && ge_tid() == 0) ge_finish_item(P, run, env);  // seed[] / episode[] now name the new episode (refill: the image is valid)
-    if constexpr (RAGGED) {
-      const int cls = ge_slot_class(R, env);
-      const GeParams &C = R.classes[cls];
-      if (C.n > 64) {  // uniform: the generic kernel takes the slot (global id)
-        if (ge_tid() == 0) { int k = atomicAdd(&P.buf.work_count[0], 1); P.buf.work_list[k] = env; }
-        continue;
-      }
-      ge_features64_env(C, env - R.class_start[cls], pre + nblk + 1, P.buf.work_count, P.buf.work_list, env);
-    } else {
-      ge_features64_env(P, env, pre + nblk + 1, P.buf.work_count, P.buf.work_list, env);
+  for (int base = 0;; base += GE_F64_ITEMS) {
+    const int tid = ge_tid_fresh();
+    if (queue) {  // the prefix scan is one wave wide
+      if (tid < GE_WAVE) ge_queue_prefix_wave(P, pre, tid);
+      ge_sync();
+      count = pre[nblk];
     }
+    const int total = count + (count + 3) / 4;
+    if (ge_bid() + (int64_t)base * ge_gdim() >= total) break;  // (uniform)
+    if (tid < GE_F64_ITEMS * 4) {
+      const int64_t q = ge_bid() + (int64_t)(base + (tid >> 2)) * ge_gdim();
+      const int sub = tid & 3;
+      int qi = -1;
+      if (q < count) qi = sub == 0 ? (int)q : -1;
+      else if (q < total) { const int64_t k = 4 * (q - count) + sub; qi = k < count ? (int)k : -1; }
+      items[tid] = qi < 0 ? -1 : (queue ? ge_queue_slot(P, pre, qi) : qi);
+    }
+    ge_sync();
+    for (int i = 0; i < GE_F64_ITEMS; i++) {
+      const int64_t q = ge_bid() + (int64_t)(base + i) * ge_gdim();
+      if (q >= total) break;  // (uniform)
+      if (q < count) {  // walk item
+        const int env = items[4 * i];
+        if (queue && ge_tid() == 0) ge_finish_item(P, run, env);  // seed[] / episode[] now name the new episode (refill: the image is valid)
+        if constexpr (RAGGED) {
+          const int cls = ge_slot_class(R, env);
+          const GeParams &C = R.classes[cls];
+          if (C.n > 64) {  // uniform: the generic kernel takes the slot (global id)
+            if (ge_tid() == 0) { int k = atomicAdd(&P.buf.work_count[0], 1); P.buf.work_list[k] = env; }
+            continue;
+          }
+          ge_f64_walk_env(C, env - R.class_start[cls], ovf_flag, P.buf.work_count, P.buf.work_list, env);
+        } else {
+          ge_f64_walk_env(P, env, ovf_flag, P.buf.work_count, P.buf.work_list, env);
+        }
+      } else {  // node item: a slot per wave
+        const int t2 = ge_tid_fresh();
+        const int wv = t2 >> 6, lane = t2 & (GE_WAVE - 1);
+        const int env = items[4 * i + wv];
+        if (env >= 0) {
+          if constexpr (RAGGED) {
+            const int cls = ge_slot_class(R, env);
+            const GeParams &C = R.classes[cls];
+            if (C.n <= 64) ge_f64_node_env(C, env - R.class_start[cls], ge_dyn_smem() + wv * ge_f64_node_wave_bytes(C.E, 0), lane);
+          } else {
+            ge_f64_node_env(P, env, ge_dyn_smem() + wv * ge_f64_node_wave_bytes(P.E, P.env_type == GE_TSP), lane);
+          }
+        }
+        ge_sync();  // (the next item, or the next chunk's queue prefix, rewrites the LDS)
+      }
+    }
+    ge_sync();
   }
 }

@@ -45,6 +45,14 @@ GE_DEV uint64_t ge_quad_gather16(uint32_t v) {
   const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, true), b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true);
   return (uint64_t)((b0 & 0xffffu) | (b1 << 16)) | ((uint64_t)((b2 & 0xffffu) | (b3 << 16)) << 32);
 }
+// OR over the eight lanes of an octet (lanes 8k .. 8k+7 of the wave), the result in every one of them: two quad_perm exchanges and a
+// row_half_mirror (lane i of the eight <-> lane 7 - i), three DPP moves, no LDS.  Every lane of the octet must execute it.
+GE_DEV uint32_t ge_oct_or32(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);
+  return v;
+}
 // fire-and-forget LDS adds (ds_add_u32 / ds_add_f64, no return value, nothing to wait for)
 GE_DEV void ge_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 GE_DEV void ge_lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }

@@ -68,7 +68,7 @@ struct Fiber {
   ucontext_t ctx;
   char *stack = nullptr;
   bool done = true;
-  int waiting = 0;  // 0 runnable, 1 block barrier, 2 wave collective, 3 quad rendezvous
+  int waiting = 0;  // 0 runnable, 1 block barrier, 2 wave collective, 3 quad rendezvous, 4 octet rendezvous
 };
 
 struct Block {
@@ -171,6 +171,11 @@ inline void run_block(int bid, int gdim, int nthreads, size_t smem_bytes) {
       for (int t = q0; t < nthreads && t < q0 + kQuad; t++) if (!b.fib[t].done) { ql++; if (b.fib[t].waiting == 3) qw++; }
       if (ql && qw == ql) { for (int t = q0; t < nthreads && t < q0 + kQuad; t++) if (b.fib[t].waiting == 3) b.fib[t].waiting = 0; released = true; }
     }
+    for (int q0 = 0; q0 < nthreads; q0 += 8) {  // octets (the n <= 64 feature kernel: eight lanes per BFS source)
+      int ql = 0, qw = 0;
+      for (int t = q0; t < nthreads && t < q0 + 8; t++) if (!b.fib[t].done) { ql++; if (b.fib[t].waiting == 4) qw++; }
+      if (ql && qw == ql) { for (int t = q0; t < nthreads && t < q0 + 8; t++) if (b.fib[t].waiting == 4) b.fib[t].waiting = 0; released = true; }
+    }
     if (!progressed && !released) {
       if (getenv("GE_EMU_DEBUG_DEADLOCK"))  // which lanes wait for what (1 block barrier, 2 wave collective, 3 quad rendezvous)
         for (int t = 0; t < nthreads && t < 64; t++) if (!b.fib[t].done) fprintf(stderr, "[hip_emu] block %d lane %d waits for %d\n", bid, t, b.fib[t].waiting);
@@ -257,6 +262,18 @@ GE_DEV uint64_t ge_quad_gather16(uint32_t v) {
   uint64_t r = 0;
   for (int k = 0; k < 4; k++) r |= (uint64_t)(gslot[q0 + k] & 0xffffu) << (16 * k);
   ge_quad_sync();
+  return r;
+}
+GE_DEV void ge_oct_sync() { ge_emu::Block &b = ge_emu::blk(); b.fib[b.cur].waiting = 4; ge_emu::yield_to_sched(); }
+GE_DEV uint32_t ge_oct_or32(uint32_t v) {
+  ge_emu::Block &b = ge_emu::blk();
+  static uint32_t oslot[ge_emu::kMaxThreads];
+  oslot[b.cur] = v;
+  const int q0 = b.cur & ~7;
+  ge_oct_sync();
+  uint32_t r = 0;
+  for (int k = 0; k < 8; k++) r |= oslot[q0 + k];
+  ge_oct_sync();
   return r;
 }
 GE_DEV uint32_t ge_quad_xor1(uint32_t v) { return ge_quad_xchg(v, 1); }
