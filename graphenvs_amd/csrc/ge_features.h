@@ -390,14 +390,15 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
 #define GE_F64_LST 16                    // level starts kept per source (GE_F64_LV + 1 <= GE_F64_LST)
 #define GE_F64_ITEMS 16                  // items a workgroup looks up per queue-prefix rebuild
 static_assert(GE_F64_LV + 1 <= GE_F64_LST, "level starts");
+static_assert(GE_F64_INV <= 256, "path counts are kept as bytes");
 // per-wave area of a walk item
 // (rows of S and sigma carry a 65th entry that stays zero: the pulls read GE_F64_U entries of a set per trip and point the ones that
 // do not exist at it -- coeff = inv[0] + 0.0 = +0.0 leaves a sum as it is)
 #define GE_F64_SS 65                                              // row stride of S (float64)
-#define GE_F64_SG 66                                              // row stride of sigma (u16; whole dwords)
+#define GE_F64_SG 68                                              // row stride of sigma (bytes: every count below GE_F64_INV <= 256; whole dwords)
 #define GE_F64_A_S 0                                              // double  S[8][65]
-#define GE_F64_A_SIG (GE_F64_A_S + GE_F64_SB * GE_F64_SS * 8)     // u16 sigma[8][66]
-#define GE_F64_A_LVL (GE_F64_A_SIG + GE_F64_SB * GE_F64_SG * 2)   // u64 lvl[GE_F64_LV][8]
+#define GE_F64_A_SIG (GE_F64_A_S + GE_F64_SB * GE_F64_SS * 8)     // u8 sigma[8][68]
+#define GE_F64_A_LVL (GE_F64_A_SIG + GE_F64_SB * GE_F64_SG)       // u64 lvl[GE_F64_LV][8]
 #define GE_F64_A_ORD (GE_F64_A_LVL + GE_F64_LV * GE_F64_SB * 8)   // u8 ord[8][64]: the nodes of a search in (level, node) order
 #define GE_F64_A_LST (GE_F64_A_ORD + GE_F64_SB * 64)              // u8 lst[8][GE_F64_LST]: where level d starts in ord
 #define GE_F64_A_BYTES (GE_F64_A_LST + GE_F64_SB * GE_F64_LST)
@@ -435,7 +436,7 @@ GE_DEV void ge_f64_next_bits(uint32_t &b, int (&idx)[GE_F64_U]) {
   }
 }
 // sum of the path counts row[i] over the set bits i of the 64-bit set p (integers: exact in any order)
-GE_DEV uint32_t ge_f64_sum_counts(const uint16_t *row, uint64_t p) {
+GE_DEV uint32_t ge_f64_sum_counts(const uint8_t *row, uint64_t p) {
   uint32_t acc = 0u;
   for (uint32_t b = (uint32_t)p; b;) {
     int ix[GE_F64_U]; uint32_t r[GE_F64_U];
@@ -462,7 +463,7 @@ GE_DEV uint32_t ge_f64_sum_counts(const uint16_t *row, uint64_t p) {
                         // of that one addition (exact for a node without successors)
 #endif
 template <int BASE>
-GE_DEV double ge_f64_sum_coeff_half(const uint16_t *sigrow, const double *Srow, const double *inv, uint32_t b, double acc) {
+GE_DEV double ge_f64_sum_coeff_half(const uint8_t *sigrow, const double *Srow, const double *inv, uint32_t b, double acc) {
 #if GE_F64_COEFF
   while (b) {
     int ix[GE_F64_U]; double sw[GE_F64_U];
@@ -499,7 +500,7 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
   double *const inv = (double *)(sm + GE_F64_W_INV), *const clos = (double *)(sm + GE_F64_W_CLOS);
   unsigned char *const area = sm + GE_F64_W_AREA + wv * GE_F64_A_BYTES;
   double *const S = (double *)(area + GE_F64_A_S);
-  uint16_t *const sig = (uint16_t *)(area + GE_F64_A_SIG);
+  uint8_t *const sig = (uint8_t *)(area + GE_F64_A_SIG);
   uint64_t *const lvl = (uint64_t *)(area + GE_F64_A_LVL);
   uint8_t *const ord = (uint8_t *)(area + GE_F64_A_ORD), *const lst = (uint8_t *)(area + GE_F64_A_LST);
   GE_STAMP(11);
@@ -509,12 +510,8 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
   ge_sync();
   GE_STAMP(12);
   const int sl = lane >> 3, o = lane & 7;  // source of the sub-batch, lane of its octet
-  // the adjacency rows of this lane's eight nodes (the same in both rounds)
-  uint32_t rlo[8], rhi[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) { const uint64_t r = abits[8 * o + j]; rlo[j] = (uint32_t)r; rhi[j] = (uint32_t)(r >> 32); }
   const uint64_t below_o = (1ull << (8 * o)) - 1ull;  // the nodes of the octet lanes below this one
-  uint16_t *const sigrow = sig + sl * GE_F64_SG; double *const Srow = S + sl * GE_F64_SS;
+  uint8_t *const sigrow = sig + sl * GE_F64_SG; double *const Srow = S + sl * GE_F64_SS;
   uint8_t *const ordrow = ord + sl * 64, *const lstrow = lst + sl * GE_F64_LST;
   double bc = 0.0;  // wave 0: betweenness of node `lane`, sources added in order
   bool ovf = false;
@@ -525,6 +522,10 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
     uint64_t vis = src ? (1ull << s) : 0ull, cur = vis;
     int D = 0, reach = 1, start = src ? 1 : 0, Dw = 0; int64_t tot = 0;
     if (o == 0) { lvl[sl] = cur; lstrow[0] = 0; lstrow[1] = (uint8_t)start; if (src) ordrow[0] = (uint8_t)s; }
+    // the adjacency rows of this lane's eight nodes (registers during the level search only: the pulls need the room)
+    uint32_t rlo[8], rhi[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint64_t rw = abits[8 * o + j]; rlo[j] = (uint32_t)rw; rhi[j] = (uint32_t)(rw >> 32); }
     for (int d = 1; !(GE_F64_ABL & 32); d++) {
       const uint32_t cb = (uint32_t)(cur >> (8 * o)) & 0xffu;  // which of my eight nodes are in the current level
       uint32_t nlo = 0u, nhi = 0u;
@@ -554,7 +555,7 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
     }
     if (r > 0) ge_sync();  // wave 0 has added the previous round's dependencies: S and sigma may be rewritten
     // ---- zero the round's counts and dependency sums (a node no search reaches keeps 0 x 0.0)
-    for (int i = lane; i < GE_F64_SB * GE_F64_SG / 2; i += GE_WAVE) ((uint32_t *)sig)[i] = 0u;
+    for (int i = lane; i < GE_F64_SB * GE_F64_SG / 4; i += GE_WAVE) ((uint32_t *)sig)[i] = 0u;
     for (int i = lane; i < GE_F64_SB * GE_F64_SS; i += GE_WAVE) S[i] = 0.0;
     ge_wave_sync();
     if (o == 0 && src) sigrow[s] = 1;
@@ -569,7 +570,7 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
           const int v = ordrow[k];
           const uint64_t p = abits[v] & prev;
           const uint32_t acc = ge_f64_sum_counts(sigrow, p);
-          sigrow[v] = (uint16_t)acc;      // (<= 64 x (GE_F64_INV - 1))
+          sigrow[v] = (uint8_t)(acc < 255u ? acc : 255u);
           if (acc >= (uint32_t)GE_F64_INV) ovf = true;  // no reciprocal in the table: the generic kernel takes the slot
         }
       }
@@ -580,7 +581,7 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
     // integer) path count comes from the LDS table, one float64 add instead of a multiply, an add and a division
     const bool deep2 = ge_ballot(ovf) != 0ull;
 #if GE_F64_COEFF
-    if (!deep2) for (int i = lane; i < GE_F64_SB * 64; i += GE_WAVE) { const int a = (i >> 6) * GE_F64_SS + (i & 63), g = (i >> 6) * GE_F64_SG + (i & 63); S[a] = inv[sig[g]]; }
+    if (!deep2) for (int i = lane; i < GE_F64_SB * 64; i += GE_WAVE) { const int a = (i >> 6) * GE_F64_SS + (i & 63), g = (i >> 6) * GE_F64_SG + (i & 63); S[a] = inv[sig[g] < GE_F64_INV ? sig[g] : 0]; }
     ge_wave_sync();
 #endif
     for (int d = Dw - 1; d >= 1 && !deep2 && !(GE_F64_ABL & 2); d--) {
@@ -609,7 +610,7 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
 #pragma unroll 1
       for (int w = 0; w < GE_F64_WAVES; w++) {
         const unsigned char *const aw = sm + GE_F64_W_AREA + w * GE_F64_A_BYTES;
-        const uint16_t *const sgw = (const uint16_t *)(aw + GE_F64_A_SIG) + lane; const double *const Sw = (const double *)(aw + GE_F64_A_S) + lane;
+        const uint8_t *const sgw = (const uint8_t *)(aw + GE_F64_A_SIG) + lane; const double *const Sw = (const double *)(aw + GE_F64_A_S) + lane;
         uint32_t sg[GE_F64_SB]; double sv[GE_F64_SB];
 #pragma unroll
         for (int k = 0; k < GE_F64_SB; k++) { sg[k] = sgw[GE_F64_SG * k]; sv[k] = Sw[GE_F64_SS * k]; }
@@ -776,7 +777,7 @@ GE_KERNEL ge_k_feat_combine(GeParams P, GeRagged R, GeRun run) {
 // slot of a class with n > 64 goes straight to work_list.  A workgroup takes the items bid, bid + grid, ...; in queue mode it looks
 // up the slots of GE_F64_ITEMS of them at a time (the queue prefix overlays the item bodies in LDS and is rebuilt per chunk).
 #ifndef GE_F64_WPS
-#define GE_F64_WPS 5  // waves per SIMD the register allocation of the n <= 64 feature kernel is held to (0: the compiler's choice)
+#define GE_F64_WPS 6  // waves per SIMD the register allocation of the n <= 64 feature kernel is held to (0: the compiler's choice)
 #endif
 #if GE_F64_WPS > 0
 #define GE_F64_KERNEL GE_KERNEL_LB(GE_F64_THREADS, GE_F64_WPS)

@@ -1376,12 +1376,15 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
             lost = (atomicOr((unsigned long long *)&c.abits[a * W + (b >> 6)], bit) & bit) != 0;
           }
           bool dup = false;  // the same edge proposed earlier in this round
-          if (!early || ge_ballot(lost)) {
-            for (uint64_t rem = EL; rem;) {
+          // (an early round only has to look at the keys a lane LOST on -- an edge proposed once has no earlier occurrence --: one or
+          // two trips where the walk over every eligible lane took ~16, each a shuffle and a ballot on the critical path of the slot)
+          const uint64_t LOST = early ? ge_ballot(lost) : EL;
+          if (LOST) {
+            for (uint64_t rem = LOST; rem;) {
               const int l0 = ge_ctz64(rem);
               const uint32_t k0 = ge_shfl_u32(key, l0);
               const uint64_t same = ge_ballot(elig && key == k0);
-              if (elig && key == k0 && lane != l0) dup = true;
+              if (elig && key == k0 && lane != ge_ctz64(same)) dup = true;  // every proposer but the first in stream order
               rem &= ~same;
             }
           }
