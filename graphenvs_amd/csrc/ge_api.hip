@@ -137,8 +137,6 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   if (t == GE_DISTRIBUTION_CENTER && (cfg->n_dests < 0 || cfg->n_dests > n)) return fail(GE_E_BADARG, "target_count must be in [0, n_nodes]");
   if (t == GE_DISTRIBUTION_CENTER && !(cfg->max_distance >= 0.0)) return fail(GE_E_BADARG, "max_distance must be >= 0");
   if (t == GE_MULTICAST_ROUTING && (cfg->parenting < 1 || cfg->parenting > 4)) return fail(GE_E_BADARG, "Invalid parenting type (multicast_routing.py:34-35)");
-  // not built yet
-  if (t == GE_PERISHABLE_DELIVERY && cfg->weighted && n > GE_NP_EARLY_MAX) return fail(GE_E_UNSUPPORTED, "weighted PerishableProductDelivery is built for n_nodes <= 256 (its placement reads the delay matrix, which lives in LDS)");
 
   P.env_type = t; P.B = cfg->num_envs; P.n = n; P.m = m; P.E = 2 * m; P.W = (n + 63) / 64; P.ng = ng;
   const bool edge_env = (t == GE_STEINER_TREE || t == GE_MULTICAST_ROUTING);

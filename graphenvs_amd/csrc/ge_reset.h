@@ -422,12 +422,10 @@ GE_DEV void ge_np_draws(const GeParams &P, const GeRctx &c, uint32_t *mt, int &n
 // three at n = 512.  (The draw-by-draw form tested every accepted draw against the adjacency matrix: a division and an LDS read per
 // draw, 262 144 draws per slot at n = 512.)  Needs the topology: c.abits, c.rowptr; uses c.elist (free once the CSR is built) for the
 // wanted cells and c.dist for the per-row offsets.  One wave.
-GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
-  const int n = P.n, W = P.W, m = P.m, total = n * n;
-  const uint64_t below = (1ull << lane) - 1ull;
-  // wanted cells, ascending: edge (u, v), u < v, is number up[u] + |{w in N(u): u < w < v}| where up[u] counts the edges of smaller rows
-  uint32_t *tcell = c.elist;
-  uint8_t *tcode = (uint8_t *)c.wm;  // the code of wanted cell number t (the numpy wave drew nothing into wm: no matrix at this size)
+// wanted cells of the n x n draw, ascending, into tcell[m]: edge (u, v), u < v, is number up[u] + |{w in N(u): u < w < v}| where
+// up[u] (left in c.dist[u]) counts the edges of smaller rows.  Needs the adjacency bit rows only.
+GE_DEV void ge_np_edge_cells(const GeParams &P, const GeRctx &c, uint32_t *tcell, int lane) {
+  const int n = P.n, W = P.W;
   {
     int carry = 0;
     for (int k0 = 0; k0 < n; k0 += GE_WAVE) {
@@ -447,6 +445,24 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
     }
     ge_wave_sync();
   }
+}
+// number of the cell of edge {u, v} in that order (ge_np_edge_cells has run: c.dist = up[])
+GE_DEV int ge_np_edge_number(const GeRctx &c, int W, int u, int v) {
+  const int a = u < v ? u : v, b = u < v ? v : u;
+  int t = c.dist[a];
+  for (int w = a >> 6; w <= (b >> 6); w++) {
+    uint64_t bits = c.abits[a * W + w];
+    if (w == (a >> 6)) bits &= ~((2ull << (a & 63)) - 1ull);
+    if (w == (b >> 6)) bits &= (1ull << (b & 63)) - 1ull;
+    t += ge_popc64(bits);
+  }
+  return t;
+}
+// the scan: n * n masked draws of randint(3, 10), of which only the ones that land on a wanted cell are kept -- tcode[t] = the code
+// of wanted cell number t
+GE_DEV void ge_np_draws_cells(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane, const uint32_t *tcell, uint8_t *tcode) {
+  const int n = P.n, m = P.m, total = n * n;
+  const uint64_t below = (1ull << lane) - 1ull;
   // The hot loop touches no graph structure: the wanted cells are held 64 at a time in a register (lane j: cell number t0 + j, read
   // with v_readlane), and the accepted draw that lands on one is stored by its lane as tcode[t]; the codes go to their two slots
   // of the ascending-neighbour order afterwards, one lane per edge.
@@ -528,13 +544,25 @@ GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, 
   }
   ge_wave_sync();
   GE_STAMP_B0(8);
-  for (int e = lane; e < m; e += GE_WAVE) {  // delay[u, v] of edge number e, to both directions
+}
+// delay[u, v] of edge number e to both directions of the ascending-neighbour order (needs the CSR row starts)
+GE_DEV void ge_np_codes_to_rows(const GeParams &P, const GeRctx &c, const uint32_t *tcell, const uint8_t *tcode, int lane) {
+  const int n = P.n, W = P.W, m = P.m;
+  for (int e = lane; e < m; e += GE_WAVE) {
     const uint32_t cell = tcell[e];
     const int u = (int)(cell / (uint32_t)n), v = (int)(cell - (uint32_t)u * (uint32_t)n);
     const uint8_t code = tcode[e];
     c.wsort[ge_sorted_pos(c, W, u, v)] = code; c.wsort[ge_sorted_pos(c, W, v, u)] = code;
   }
   ge_wave_sync();
+}
+// graphs too large for the dense matrix, after the topology and its CSR exist: cells, scan, codes to their rows
+GE_DEV void ge_np_draws_edges(const GeParams &P, const GeRctx &c, uint32_t *mt, int &nppos, int lane) {
+  uint32_t *tcell = c.elist;
+  uint8_t *tcode = (uint8_t *)c.wm;  // the code of wanted cell number t (the numpy wave drew nothing into wm: no matrix at this size)
+  ge_np_edge_cells(P, c, tcell, lane);
+  ge_np_draws_cells(P, c, mt, nppos, lane, tcell, tcode);
+  ge_np_codes_to_rows(P, c, tcell, tcode, lane);
 }
 
 // first `need` entries of legacy numpy permutation(pn) into c.perm (np.random.choice(pn, k, replace=False) is its first k entries)
@@ -982,8 +1010,10 @@ GE_DEV void ge_ppd_dist(const GeParams &P, const GeRctx &c, int p, double *dist,
         for (int w = 0; w < W; w++)
           for (uint64_t r = c.abits[v * W + w]; r; r &= r - 1) {
             const int u = w * 64 + ge_ctz64(r);
-            const int cell = (u < v ? u : v) * n + (u < v ? v : u);
-            const double d = dist[u] + (P.weighted ? ge_wlut((int)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u)) : 1.0);
+            double wuv = 1.0;
+            if (P.weighted && P.np_early) { const int cell = (u < v ? u : v) * n + (u < v ? v : u); wuv = ge_wlut((int)((c.wm[cell >> 3] >> (4 * (cell & 7))) & 15u)); }
+            else if (P.weighted) wuv = ge_wlut((int)((const uint8_t *)c.wm)[ge_np_edge_number(c, W, u, v)]);  // above 256 nodes: the codes of the edges only, by edge number
+            const double d = dist[u] + wuv;
             if (d < best) best = d;
           }
         if (best < dist[v]) { dist[v] = best; improved = true; }
@@ -1430,9 +1460,12 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       if (ok && t == GE_TSP) ok = ge_connected(c, ng, W, 0, lane);  // tsp.py:69-71
       if (ok && t == GE_PERISHABLE_DELIVERY) {  // perishable_product_delivery.py:75-111: weights and placement belong to the attempt
         double rnd;
-        if (ppd_attempt == 0) { ge_sync(); ppd_pos = c.misc[2]; rnd = *(const double *)c.misc; }  // join: the numpy wave drew the first matrix and rand()
-        else {
-          if (P.weighted) { for (int i = lane; i < (n * n + 7) / 8; i += GE_WAVE) c.wm[i] = 0u; ge_wave_sync(); ge_np_draws(P, c, c.mt2, ppd_pos, n * n, lane, 0); }
+        const bool late = P.weighted && !P.np_early;  // above 256 nodes the n x n delay matrix does not fit LDS: this wave draws it for every
+                                                      // attempt and keeps the codes of the attempt's edges only (c.tmp is free inside the loop)
+        if (ppd_attempt == 0) { ge_sync(); if (late) ppd_pos = pos0(1); else { ppd_pos = c.misc[2]; rnd = *(const double *)c.misc; } }  // join: the numpy wave drew the first matrix and rand()
+        if (ppd_attempt > 0 || late) {
+          if (late) { ge_np_edge_cells(P, c, c.tmp, lane); ge_np_draws_cells(P, c, c.mt2, ppd_pos, lane, c.tmp, (uint8_t *)c.wm); }
+          else if (P.weighted) { for (int i = lane; i < (n * n + 7) / 8; i += GE_WAVE) c.wm[i] = 0u; ge_wave_sync(); ge_np_draws(P, c, c.mt2, ppd_pos, n * n, lane, 0); }
           const uint32_t ra = ge_np_next(c.mt2, ppd_pos, lane), rb = ge_np_next(c.mt2, ppd_pos, lane);
           rnd = ((double)(int32_t)(ra >> 5) * 67108864.0 + (double)(int32_t)(rb >> 6)) / 9007199254740992.0;
         }
@@ -1582,6 +1615,9 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       }
     } else if (t == GE_MAX_INDEPENDENT_SET) {
       for (int v = lane; v < n; v += GE_WAVE) c.fill[v] = P.weighted ? (int)((const uint8_t *)c.wm)[v] : 10;
+    } else if (P.weighted && t == GE_PERISHABLE_DELIVERY) {  // drawn inside the rejection loop (codes by edge number in wm): to their rows
+      ge_np_edge_cells(P, c, c.elist, lane);
+      ge_np_codes_to_rows(P, c, c.elist, (const uint8_t *)c.wm, lane);
     } else if (P.weighted && matrix_w) {  // n too large for the dense matrix: draw now, codes land by rank
       int nppos = pos0(1);
       ge_np_draws_edges(P, c, c.mt2, nppos, lane);

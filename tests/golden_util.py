@@ -52,7 +52,20 @@ def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True
     meta = case["meta"]
     env_id, kwargs = meta["env_id"], meta["kwargs"]
     n = kwargs["n_nodes"]
-    stats = dict(resets=0, steps=0, inexact_feature_values=0)
+    stats = dict(resets=0, steps=0, inexact_feature_values=0, inexact_rewards=0)
+    # spatial TSP (tsp.py:85): the reference squares coordinate differences with Python's float ** 2 = libm pow(d, 2.0), which under
+    # glibc differs from d * d in the last bit for about one value in 1 200; the engine and the checker multiply.  The float64 edge
+    # weight sqrt(dx**2 + dy**2) can therefore differ by an ulp, and rewards / costs built from it are compared within north_star's
+    # 1e-6 (and, tighter, 1e-12 relative) instead of exactly; fixture tsp_n12_m30_p1_spatial_pow2 holds seeds where it happens
+    loose = bool(kwargs.get("spatial", False))
+
+    def same_f64(got, want):
+        if got == want or (np.isnan(got) and np.isnan(want)):
+            return True
+        if not loose:
+            return False
+        stats["inexact_rewards"] += 1
+        return abs(got - want) <= 1e-6 and abs(got - want) <= 1e-12 * max(1.0, abs(want))
 
     def obs_equal(got, want, what):
         if feature_ulps == 0 or feature_slice is None:
@@ -82,7 +95,7 @@ def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True
                 obs, r, d, trunc, info = env.step(a)
                 stats["steps"] += 1
                 tag = f"{meta['case']} seed {seed} policy {pol} t {t}"
-                assert float(r) == float(case[pol + "_rewards"][si, t]), tag + f": reward {r} != {case[pol + '_rewards'][si, t]}"
+                assert same_f64(float(r), float(case[pol + "_rewards"][si, t])), tag + f": reward {r} != {case[pol + '_rewards'][si, t]}"
                 assert bool(d) == bool(case[pol + "_dones"][si, t]), tag + ": done"
                 assert trunc is False or not bool(trunc)
                 want_mask = unpack_mask(case[pol + "_masks_packed"][si, t], A)
@@ -103,7 +116,7 @@ def replay_case(case, make_env, policies=("first", "rand"), check_heuristic=True
                     want_solved = int(case[pol + "_solved"][si])
                     got_solved = int(bool(info["solved"])) if "solved" in info else -1
                     assert got_solved == want_solved, f"{meta['case']} seed {seed} {pol}: solved"
-                    assert float(info["solution_cost"]) == float(case[pol + "_solution_cost"][si]), f"{meta['case']} seed {seed} {pol}: solution_cost"
+                    assert same_f64(float(info["solution_cost"]), float(case[pol + "_solution_cost"][si])), f"{meta['case']} seed {seed} {pol}: solution_cost"
                     h, ref_h = float(info["heuristic_solution"]), float(case[pol + "_heuristic_solution"][si])
                     kind = heuristic_kind(env_id, kwargs)
                     what = f"{meta['case']} seed {seed} {pol}: heuristic {h} vs reference {ref_h}"

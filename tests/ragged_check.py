@@ -88,3 +88,87 @@ def _episode(member, j):
             return int(c.t["episode"][j - lo])
         lo += c.num_envs
     raise IndexError(j)
+
+
+def check_config5_full_size(ge, oracle, device, per_id=16384, sampled=16, steps=40, seed=11):
+    """BASELINE config 5 at its real size -- per env id `per_id` slots whose n is drawn from U{32..512} (every size occurs: 481
+    classes), m = 3n, the batch bench.py times -- : invariants over EVERY slot after every step (transition counters, mask bytes ==
+    mask bits, episode counters against the terminations seen) and `sampled` slots per id replayed on the oracle step by step,
+    policy draws and every regenerated observation included."""
+    rng = np.random.default_rng(0)
+    pick = np.random.default_rng(1)
+    members, plans = [], []
+    for eid, extra in (("ShortestPath-v0", {}), ("MaxIndependentSet-v0", {}), ("DensestSubgraph-v0", dict(parenting=1))):
+        ns = rng.integers(32, 513, per_id)
+        sizes = [(int((ns == n).sum()), int(n), 3 * int(n)) for n in np.unique(ns)]
+        m = ge.RaggedVectorEnv(eid, sizes, device=device, **extra)
+        assert m.num_envs == per_id and len(m.classes) == len(sizes)
+        members.append(m)
+        # sampled global slots: the extremes of the size range always among them
+        starts = np.cumsum([0] + [b for b, _, _ in sizes])
+        slots = sorted(set([0, per_id - 1] + pick.integers(0, per_id, sampled - 2).tolist()))
+        plan = []
+        for g in slots:
+            c = int(np.searchsorted(starts, g, side="right") - 1)
+            plan.append(dict(slot=g, cls=c, i=g - int(starts[c]), n=sizes[c][1], m=sizes[c][2],
+                             ref=oracle.OracleEnv(eid, n_nodes=sizes[c][1], n_edges=sizes[c][2], **extra), t=0, ep=0))
+        plans.append((eid, extra, plan))
+    mixed = ge.MixedVectorEnv(members)
+    graphs, infos = mixed.reset(seed=seed)
+
+    def check_obs(member, g, p, what):
+        lo, hi = int(member.ptr[p["slot"]]), int(member.ptr[p["slot"] + 1])
+        assert hi - lo == p["n"], what
+        assert np.array_equal(g.x[lo:hi].cpu().numpy(), p["ref"].nodes()), what + " (nodes)"
+        cls = member.classes[p["cls"]]
+        E = 2 * p["m"]
+        # the class's view of the shared [2, Ne] slab starts at its first edge of row 0
+        first = (cls.t["edge_index"].data_ptr() - member.edge_index.data_ptr()) // 8 + p["i"] * E
+        rows = member.edge_index[:, first:first + E].cpu().numpy() - lo
+        assert np.array_equal(rows.T, p["ref"].edge_links()), what + " (edge links)"
+        assert np.array_equal(member.edge_attr[first:first + E].cpu().numpy(), p["ref"].edges()), what + " (edge attributes)"
+
+    for (eid, extra, plan), member, g in zip(plans, members, graphs):
+        for p in plan:
+            p["ref"].reset(seed=seed + p["slot"])
+            check_obs(member, g, p, f"{eid} slot {p['slot']} after reset")
+            assert np.array_equal(member.classes[p["cls"]].mask[p["i"]].cpu().numpy(), p["ref"].mask())
+    seen_terms = [0, 0, 0]
+    for k in range(steps):
+        acts = mixed.sample_random_actions(policy_seed=5)
+        obs, rew, term, trunc, info = mixed.step(acts)
+        for mi, ((eid, extra, plan), member) in enumerate(zip(plans, members)):
+            a, rw, tm = acts[mi], rew[mi], term[mi]
+            seen_terms[mi] += int(tm.sum())
+            # ---- every slot
+            packed = member.g["slot_rec"][:, 1]
+            assert int(((packed >> 32) & 0xFFFFFFFF).sum()) == member.num_envs * (k + 1), (eid, k)  # transitions survive regenerations
+            assert int(member.g["episode"].sum()) == seen_terms[mi], (eid, k)                      # same-step autoreset: one new episode per termination
+            assert int(((packed >> 16) & 0xFF).max()) == 0, (eid, k)                                # nobody is frozen or pending
+            for cls in member.classes[:: max(1, len(member.classes) // 40)]:                        # mask bytes == mask bits (a spread of classes)
+                A = cls.A
+                bits = cls.t["mask_bits"]
+                unpacked = ((bits.unsqueeze(-1) >> torch.arange(64, device=bits.device)) & 1).reshape(cls.num_envs, -1)[:, :A].to(torch.uint8)
+                assert torch.equal(unpacked, cls.t["mask"]), (eid, cls.n, k)
+            # ---- the sampled slots, on the oracle
+            a_np, rw_np, tm_np = a.cpu().numpy(), rw.cpu().numpy(), tm.cpu().numpy()
+            for p in plan:
+                g = p["slot"]
+                want_a = oracle.policy_pick(p["ref"].mask(), 5, g, p["t"])
+                assert int(a_np[g]) == want_a, (eid, g, k)
+                _, rr, dd, _, _ = p["ref"].step(int(a_np[g]))
+                p["t"] += 1
+                assert rr == rw_np[g] and dd == bool(tm_np[g]), (eid, g, k)
+                if dd:
+                    p["ep"] += 1
+                    p["ref"].reset(seed=(seed + g + member.num_envs * p["ep"]) % 2**32)
+                    check_obs(member, obs[mi], p, f"{eid} slot {g} regenerated at step {k}")
+                assert np.array_equal(member.classes[p["cls"]].mask[p["i"]].cpu().numpy(), p["ref"].mask()), (eid, g, k)
+    for (eid, extra, plan), member, g in zip(plans, members, obs):
+        for p in plan:
+            check_obs(member, g, p, f"{eid} slot {p['slot']} at the end")
+        assert sum(p["ep"] for p in plan) > 0 or eid == "MaxIndependentSet-v0", eid  # (MaxIndependentSet episodes last n steps)
+    for m in members:
+        for c in m.classes[:1]:
+            c.check_device_errors()
+    mixed.close()

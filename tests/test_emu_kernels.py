@@ -166,7 +166,8 @@ def test_emulated_late_numpy_draws_of_large_graphs(stress):
     """-DGE_NP_EARLY_MAX=8: graphs above 8 nodes take the path of n > 256 -- the delay matrix is not materialised, the draw scan
     only counts and picks out the cells of the edges (ge_np_draws_edges)."""
     lib = stress
-    for name in ["sp_n10_m20_eval", "sp_n33_m70", "st_n10_m20_d3_eval", "mc_n10_m20_p4_eval", "dc_n10_m20_p2", "lp_n10_m20_p1"]:
+    for name in ["sp_n10_m20_eval", "sp_n33_m70", "st_n10_m20_d3_eval", "mc_n10_m20_p4_eval", "dc_n10_m20_p2", "lp_n10_m20_p1",
+                 "ppd_n10_m20", "ppd_n12_m30_p5_eval"]:  # (PerishableProductDelivery draws its matrix INSIDE the rejection loop: the codes of an attempt's edges)
         gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
 

@@ -626,3 +626,21 @@ def test_prefetch_survives_a_reset_in_the_middle_of_a_rollout(mode):
 def test_prefetch_state_dict_in_next_step_mode():
     import host_checks as hc
     hc.check_prefetch_state_dict_next_step(_ge(), "cuda", None)
+
+
+def test_config5_at_full_size_invariants_and_sampled_slots():
+    """BASELINE config 5 as bench.py times it: 3 x 16 384 slots, n ~ U{32..512} (481 size classes per env id), one multi-class
+    engine per id -- invariants over every slot, 16 sampled slots per id against the oracle (policy, rewards, masks, regenerated
+    observations)"""
+    import oracle
+    from ragged_check import check_config5_full_size
+    check_config5_full_size(_ge(), oracle, "cuda")
+
+
+def test_spatial_tsp_fixture_sits_on_the_pow_boundary():
+    """tsp_n12_m30_p1_spatial_pow2: seeds where the reference's float ** 2 (libm pow) and a multiplication differ in the last bit of an
+    edge weight.  The engine multiplies: the replay finds rewards that agree to 1e-12 relative but not exactly -- the documented
+    tolerance of spatial TSP is exercised, not vacuous"""
+    case = gu.load_case("tsp_n12_m30_p1_spatial_pow2")
+    st = gu.replay_case(case, lambda env_id, **kw: _ge().GraphEnv(env_id, **kw))
+    assert st["inexact_rewards"] > 0 and st["steps"] > 30

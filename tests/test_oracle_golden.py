@@ -17,6 +17,15 @@ def test_oracle_matches_reference_golden(name):
     assert stats["resets"] > 0
 
 
+def test_spatial_tsp_fixture_sits_on_the_pow_boundary():
+    """tsp.py:85 squares with float ** 2 (libm pow); the checker multiplies.  On the seeds of this fixture the two differ in the last
+    bit of an edge weight the policies traverse: rewards are equal within 1e-12 relative, not exactly (golden_util.replay_case)"""
+    st = gu.replay_case(gu.load_case("tsp_n12_m30_p1_spatial_pow2"), lambda env_id, **kw: oracle.OracleEnv(env_id, **kw))
+    assert st["inexact_rewards"] > 0
+    for other in ("tsp_n12_m30_p2_spatial", "tsp_n12_m30_p2_spatial_eval", "tsp_n600_m2000_p1_spatial"):  # (the other spatial fixtures are exact)
+        assert gu.replay_case(gu.load_case(other), lambda env_id, **kw: oracle.OracleEnv(env_id, **kw))["inexact_rewards"] == 0
+
+
 @pytest.mark.parametrize("name", ["sp_n10_m20_eval", "st_n10_m20_d3_eval", "ds_n10_m20_p1", "mis_n6_m8", "tsp_n10_m20_p2"])
 def test_oracle_continues_streams_on_unseeded_reset(name):
     """reset(seed=None) continues the MT19937 streams (shortest_path.py:49-52)."""
