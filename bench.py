@@ -364,8 +364,8 @@ def main():
                               "avg_launch_us": us1, "launch_floor_us": big.launch_floor_us(), "slots": B1, "kernel": cfg["kernel"]}
         big.close()
         del big
-    if single and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.config, cfg, args, budget_s=10.0)
+    # (every CPU leg comes after every GPU measurement: the OpenMP team of the C oracle keeps its threads spinning for a while after a
+    # parallel region, and a GPU loop timed right behind it -- a thousand launches from one host thread -- ran five times slower once)
     if single and args.config == "c2" and not args.no_configs:
         # BASELINE configs 3, 4, 5 on the same GPU, after (and outside) the contract's timed region: each the same loop at its own
         # default sizes, with the step-kernel roofline and a bounded cpu_baseline of its own
@@ -374,13 +374,17 @@ def main():
             sub = argparse.Namespace(**vars(args)); sub.steps = 0; sub.envs = 0; sub.prefetch = -1; sub.config = name
             try:
                 torch.cuda.empty_cache()
-                line = c5_line(sub) if name == "c5" else measure_uniform(ge, torch, name, CONFIGS[name], sub, dev, rank, world, barrier, reduce_max, prof, prof_src)
-                if not args.no_cpu_baseline:
-                    line["cpu_baseline"] = cpu_baseline(name, CONFIGS[name], sub, budget_s=6.0)
-                block[name] = line
+                block[name] = c5_line(sub) if name == "c5" else measure_uniform(ge, torch, name, CONFIGS[name], sub, dev, rank, world, barrier, reduce_max, prof, prof_src)
             except Exception as ex:  # the headline line is not hostage to a side measurement: say what failed
                 block[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         out["configs"] = block
+    if single and not args.no_cpu_baseline:
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+        out["cpu_baseline"] = cpu_baseline(args.config, cfg, args, budget_s=10.0)
+        for name, line in out.get("configs", {}).items():
+            if "error" not in line:
+                sub = argparse.Namespace(**vars(args)); sub.config = name
+                line["cpu_baseline"] = cpu_baseline(name, CONFIGS[name], sub, budget_s=6.0)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

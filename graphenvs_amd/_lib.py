@@ -151,7 +151,7 @@ def bind(lib):
     lib.ge_ragged_table_bytes.argtypes = [i32]
     lib.ge_create_ragged.restype = C.c_int
     lib.ge_create_ragged.argtypes = [C.POINTER(GeConfig), C.POINTER(GeBuffers), i32, vp, vp, vp, C.POINTER(vp)]
-    if hasattr(lib, "ge_attach_spares"):  # (tools/old_vs_new_step.py binds a library of ABI 3 for a timing comparison)
+    if hasattr(lib, "ge_attach_spares"):  # (a library of an older ABI bound for a timing comparison lacks it)
         lib.ge_attach_spares.restype = C.c_int
         lib.ge_attach_spares.argtypes = [vp, C.POINTER(GeSpares), vp]
     lib.ge_reset.restype = C.c_int

@@ -376,7 +376,7 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
                         // (G(64, 192): the largest count of a graph is 25 in the median, 47 at the 99.9th percentile)
 #endif
 #ifndef GE_F64_ABL
-#define GE_F64_ABL 0  // diagnostic ablation bits (tools/f64_phase.py; the results are wrong by construction): 1 forward pull, 2 backward pull, 4 pagerank
+#define GE_F64_ABL 0  // diagnostic ablation bits (tools/f64_variants.py "name=-DGE_F64_ABL=3"; the results are wrong by construction): 1 forward pull, 2 backward pull, 4 pagerank
                       // iterations, 8 clustering, 16 betweenness reduction, 32 level search; 0 when shipped
 #endif
 #ifndef GE_F64_U

@@ -886,9 +886,6 @@ GE_KERNEL_LB(GE_EDGE_THREADS, 1) ge_k_step_edge(GeParams P, const int64_t *actio
 #ifndef GE_ABL
 #define GE_ABL 0  // diagnostic ablation bits (tools/step_variants.py, results are wrong by construction); 0 when shipped
 #endif
-#ifndef GE_XSECTOR
-#define GE_XSECTOR 0  // 1: the flag store x[a, 0] = 1 rewrites its whole 32-byte sector (read beside the node record)
-#endif
 #define GE_ON(bit) (!(GE_ABL & (bit)))  // 1 x flag, 2 bool-mask bytes, 4 gather, 8 policy, 16 state stores, 64 output stores
 template <bool SAMPLE, bool SPARES>
 GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t policy_seed) {
@@ -929,13 +926,6 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     // ---- phase A, round 2: the record of the chosen node (its bit row and the weight codes of its 16 smallest neighbours)
     const int64_t nbase = (int64_t)i * n;
     const ulonglong2 arec = GE_ON(4) ? ((const ulonglong2 *)G.node_rec)[nbase + a] : make_ulonglong2(mb * 3, 0x3333333333333333ull);
-#if GE_XSECTOR
-    // the 32-byte sector of x that holds the flag x[a, 0] (rows are F floats: the sector also holds parts of the rows around it): read
-    // beside the record, rewritten WHOLE in phase C -- a 4-byte store into a sector nobody has read is a read-modify-write at the
-    // memory side (profiles/r01_d_step_ablation.txt: 30 of 97 us of the 1 M-slot launch)
-    float *const xsec = G.x + (((nbase + a) * (int64_t)F) & ~(int64_t)7);
-    float4 xs0 = ((const float4 *)xsec)[0], xs1 = ((const float4 *)xsec)[1];
-#endif
     const bool nbr = (arec.x >> head) & 1ull;                         // adjacency is symmetric
     const int rank = ge_popc64(arec.x & ((1ull << head) - 1ull));      // position of the head among a's neighbours
     int code = (int)((arec.y >> (4 * (rank & 15))) & 15ull);
@@ -991,16 +981,7 @@ GE_KERNEL ge_k_step_path64(GeParams P, const int64_t *actions_in, uint64_t polic
     if ((acted || st == 3) && GE_ON(16))
       ((ulonglong2 *)G.slot_rec)[i] = make_ulonglong2(ge_f64_as_u64(cost), ge_rec_make(moved ? a : head, st_out, dest, acted ? ((ts + 1) & 0xffffffffull) : ts));
     if (moved) {
-#if GE_XSECTOR
-      {
-        const int k = (int)(((nbase + a) * (int64_t)F) & 7);
-        float *e0 = (float *)&xs0, *e1 = (float *)&xs1;
-        if (k < 4) e0[k] = 1.f; else e1[k - 4] = 1.f;
-        ((float4 *)xsec)[0] = xs0; ((float4 *)xsec)[1] = xs1;
-      }
-#else
       if (GE_ON(1)) G.x[(nbase + a) * F + 0] = 1.f;
-#endif
       if (GE_ON(16)) G.node_bits[i] = vis;
     }
     if (wrote_mask && GE_ON(16)) G.mask_bits[i] = nm;

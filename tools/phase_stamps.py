@@ -20,7 +20,7 @@ L.ge_debug_read_stamps.argtypes = [C.c_void_p]
 import graphenvs_amd as ge  # noqa: E402
 
 print("flags:", extra)
-names = {24: "B walker forward", 25: "B walker backward", 0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B load+zero", 12: "B node wave: clustering+pagerank", 13: "B node wave waits for the walkers", 14: "B betweenness reduction", 15: "B pagerank", 16: "B write", 20: "A1 state load", 21: "A1 draws", 22: "A1 terminals"}
+names = {0: "A seed_py", 1: "A topology", 2: "A csr", 3: "A seed_np", 4: "A weights", 5: "A terminals", 6: "A baseline", 9: "A writeout", 11: "B walk item: stage", 12: "B walk item: two rounds (levels, path counts, dependencies, reduction)", 14: "B walk item: write", 20: "A1 state load", 21: "A1 draws", 22: "A1 terminals"}
 cfgs = [("ShortestPath-v0", dict(n_nodes=64, n_edges=192), [1, 4096, 65536])]
 if "all" in sys.argv[1:]:
     cfgs += [("SteinerTree-v0", dict(n_nodes=256, n_edges=1024, n_dests=8), [1, 2048]),
@@ -37,7 +37,8 @@ for env_id, kw, Bs in cfgs:
         print(f"{env_id} {kw} B={B}:")
         for k, nm in names.items():
             nxt = k + 1 if k != 6 else 9
-            if k == 14: nxt = 16
+            if k == 12: nxt = 14
+            if k == 14: nxt = 17
             if ts[k] and ts[nxt]:
                 print(f"    {nm:22s} {(ts[nxt]-ts[k])/100:9.1f} us")
         if ts[11] and ts[17] and ts[30] and ts[31] and ts[17] > ts[11]:  # shader clock during the n <= 64 feature kernel, measured inside it
