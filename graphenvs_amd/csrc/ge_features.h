@@ -69,9 +69,18 @@ GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat
 // on one node with four entries per trip a level of 150 nodes cost three such chains one after the other (4 400 cycles per level
 // at n = 256, tools/feat_phase_clocks.py).  DELTA false: sigma[v] = sum of front[u] (path counts: integers, exact in any order).
 // DELTA true: delta[v] = sum of sigma[v] * coeff[w] IN ROW ORDER; an entry past the end of the row adds sigma[v] * 0.0 = +0.0.
+#ifndef GE_BP_CH
+#define GE_BP_CH 4  // row entries of a pull trip (their loads in flight together)
+#endif
+#ifndef GE_BP_U
+#define GE_BP_U 1   // rows a lane takes in a pull over a level of more than 64 nodes.  (8 entries x 2 rows was round 3's choice; measured again in
+                    // round 4, full reset per slot: n = 256 m = 1 024: 2.84 -> 2.67 us with one row, n = 400: 8.59 -> 7.94 us with one row and
+                    // four entries, n = 512: 13.8 -> 13.4 -- the kernel spills at 128 VGPRs either way, and 143 VGPRs without spills at three
+                    // waves per SIMD is 40 % slower: profiles/r04_generic_feature_variants.txt)
+#endif
 template <bool DELTA, int U>
 GE_DEV void ge_brandes_pull_u(const GeFctx &c, int k0, int k1, int lane) {
-  constexpr int CH = 8;
+  constexpr int CH = GE_BP_CH;
   for (int kb = k0; kb < k1; kb += U * GE_WAVE) {
     int v[U], e[U], r1[U]; bool on[U]; double acc[U], sv[U];
 #pragma unroll
@@ -123,7 +132,7 @@ GE_DEV uint64_t ge_level_rows_or(const uint16_t *ord, const uint64_t *rows, int 
 // vector-instruction issue, and the second row of a lane costs its instructions whether or not it exists)
 template <bool DELTA>
 GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
-  if (k1 - k0 <= GE_WAVE) ge_brandes_pull_u<DELTA, 1>(c, k0, k1, lane); else ge_brandes_pull_u<DELTA, 2>(c, k0, k1, lane);
+  if (k1 - k0 <= GE_WAVE) ge_brandes_pull_u<DELTA, 1>(c, k0, k1, lane); else ge_brandes_pull_u<DELTA, GE_BP_U>(c, k0, k1, lane);
 }
 
 GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
@@ -715,8 +724,16 @@ GE_DEV int ge_slot_class(const GeRagged &R, int env) { return (int)ge_uniform_u3
 // run.items GE_ITEMS_ALL: every slot; GE_ITEMS_QUEUE: the slots of P.buf.reset_list; GE_ITEMS_LIST: work_list (fallback of the
 // fast path).  pre_off: byte offset of the queue prefix inside the dynamic LDS (behind the largest class's scratch in a multi-class
 // engine).
+#ifndef GE_GEN_WPS
+#define GE_GEN_WPS 0  // waves per SIMD the register allocation of the generic feature kernel is held to (0: the compiler's choice)
+#endif
+#if GE_GEN_WPS > 0
+#define GE_GEN_KERNEL GE_KERNEL_LB(512, GE_GEN_WPS)
+#else
+#define GE_GEN_KERNEL GE_KERNEL
+#endif
 template <bool RAGGED>
-GE_KERNEL ge_k_features(GeParams P, GeRagged R, GeRun run, int pre_off, int bucket) {
+GE_GEN_KERNEL ge_k_features(GeParams P, GeRagged R, GeRun run, int pre_off, int bucket) {
   int *pre = (int *)(ge_dyn_smem() + pre_off);
   const bool queue = run.items == GE_ITEMS_QUEUE, list = run.items == GE_ITEMS_LIST;
   int count = list ? P.buf.work_count[0] : P.B;

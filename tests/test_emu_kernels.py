@@ -162,6 +162,14 @@ def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep(stress):
         gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 
 
+def test_emulated_feature_fast_path_falls_back_when_a_path_count_has_no_reciprocal():
+    """-DGE_F64_INV=4: the n <= 64 feature kernel keeps reciprocals of the path counts 1 .. 3 only, so nearly every slot meets a count
+    without one in its forward pull (not in the level search, as with -DGE_F64_LV=3) and is recomputed by the generic kernel"""
+    lib = build_emu.load(extra=["-DGE_F64_INV=4"], out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_inv4.so"))
+    for name in ["sp_n33_m70", "sp_n64_m192_eval", "ds_n10_m20_p1", "mis_n6_m8"]:
+        gu.replay_case(gu.load_case(name), lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
+
+
 def test_emulated_late_numpy_draws_of_large_graphs(stress):
     """-DGE_NP_EARLY_MAX=8: graphs above 8 nodes take the path of n > 256 -- the delay matrix is not materialised, the draw scan
     only counts and picks out the cells of the edges (ge_np_draws_edges)."""

@@ -5,7 +5,7 @@ TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}_prof; mkdir -p $O
 # what was measured, and when: bench.py only quotes counter evidence whose source hash is that of the library it runs
 python3 -c "import sys, datetime; sys.path.insert(0, '$R'); from graphenvs_amd import _lib; print(_lib.source_hash()); print(datetime.datetime.now(datetime.timezone.utc).strftime('%Y-%m-%dT%H:%MZ'))" > $O/source_hash.txt
-bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/c2 bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-1m > $O/c2_passes.log 2>&1
+bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/c2 bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-1m --no-configs > $O/c2_passes.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 export GE_B=1048576 GE_REPS=3
 for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_COUNT"; do
@@ -15,11 +15,9 @@ done
 python3 $R/tools/pmc_summary.py $O/m1_FETCH_SIZE $O/m1_WRITE_SIZE --kernel step_path64 > $O/step_1m_traffic.txt 2>&1
 rm -rf $O/m1_FETCH_SIZE $O/m1_WRITE_SIZE
 for cfg in c3 c4; do
-  bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/$cfg bench.py --config $cfg --steps 130 --warmup 5 --no-cpu-baseline > $O/${cfg}_passes.log 2>&1
+  bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/$cfg bench.py --config $cfg --steps 130 --warmup 5 --no-cpu-baseline --no-configs > $O/${cfg}_passes.log 2>&1
 done
 cd $R
 timeout -k 10 400 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-timeout -k 10 300 python3 bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
-timeout -k 10 300 python3 bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
-timeout -k 10 400 python3 tools/bench_configs.py c5 mis ds mc dc ppd > $O/other_configs.jsonl 2> $O/other_configs.err
+timeout -k 10 400 python3 tools/bench_configs.py mis ds mc dc ppd > $O/other_configs.jsonl 2> $O/other_configs.err
 cat $O/c2/kernel_medians.txt; cut -c1-200 $O/bench_c2.json; cat $O/other_configs.jsonl
