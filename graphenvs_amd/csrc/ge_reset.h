@@ -1360,6 +1360,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
     bool failed = false;               // the G(n, m) loop hit its round cap (wave-uniform)
     const int shift = 32 - (32 - ge_clz32((uint32_t)ng));  // getrandbits(ng.bit_length())
     for (;;) {
+      GE_STAMP(29);  // (diagnostic build: the last attempt starts here)
       for (int i = lane; i < n * W; i += GE_WAVE) c.abits[i] = 0ull;
       ge_wave_sync();
       if (P.complete) {  // [nx] complete_graph: sorted rows
@@ -1447,6 +1448,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
         }
       }
       ge_wave_sync();
+      GE_STAMP(26);  // (diagnostic build: the last attempt's rounds end here)
       if (failed) break;
       // most disconnected G(n, m) samples have an isolated node (TSP also rejects a node of degree 1, tsp.py:65-68): one pass over
       // the degrees settles those attempts without the BFS; the launch lasts as long as its unluckiest slot's attempts
@@ -1456,7 +1458,9 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
         if (v < ng) for (int w = 0; w < W; w++) d += ge_popc64(c.abits[v * W + w]);
         low |= ge_ballot(v < ng && (d == 0 || (t == GE_TSP && d == 1)));
       }
+      GE_STAMP(27);
       bool ok = !low && ge_connected(c, ng, W, -1, lane);
+      GE_STAMP(28);
       if (ok && t == GE_TSP) ok = ge_connected(c, ng, W, 0, lane);  // tsp.py:69-71
       if (ok && t == GE_PERISHABLE_DELIVERY) {  // perishable_product_delivery.py:75-111: weights and placement belong to the attempt
         double rnd;

@@ -41,5 +41,7 @@ for env_id, kw, Bs in cfgs:
             if k == 14: nxt = 17
             if ts[k] and ts[nxt]:
                 print(f"    {nm:22s} {(ts[nxt]-ts[k])/100:9.1f} us")
+        if ts[29] and ts[26]:  # the LAST attempt of slot 0's G(n, m) rejection loop
+            print(f"    A last attempt: rounds {(ts[26]-ts[29])/100:.1f} us, degree pass {(ts[27]-ts[26])/100:.1f} us, connectivity {(ts[28]-ts[27])/100:.1f} us; attempts before it took {(ts[29]-ts[1])/100:.1f} us")
         if ts[11] and ts[17] and ts[30] and ts[31] and ts[17] > ts[11]:  # shader clock during the n <= 64 feature kernel, measured inside it
             print(f"    shader clock while slot 0's feature workgroup ran: {(ts[31]-ts[30]) / ((ts[17]-ts[11]) * 10.0):.3f} GHz  (s_memtime ticks / s_memrealtime 100 MHz ticks)")
