@@ -1399,7 +1399,14 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
           // A round that cannot reach edge m inserts first and asks questions later: the returning ds_or on the
           // canonical (min, max) bit tells a lane that the same edge was proposed by another lane of this round;
           // only then (about one round in four) is the first occurrence worked out exactly.
+#ifdef GE_GNM_EXACT_LAST  // diagnostic (before / after): a round that could reach edge m walks every eligible key instead of inserting first
           const bool early = cnt + ge_popc64(EL) < m;
+#else
+          // (EVERY round inserts first: a round that reaches edge m takes the bits of the pairs behind the completing draw out again --
+          // they were absent before the round, so clearing them restores it -- instead of working out the first occurrence of every
+          // eligible key one by one, ~16 shuffle + ballot trips on the critical path of each attempt's last rounds)
+          const bool early = true;
+#endif
           bool lost = false;
           if (early && elig) {
             const int a = u < v ? u : v, b = u < v ? v : u;
@@ -1428,6 +1435,10 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
           if (last_round) {  // the stream stops right after the draw that completed edge m
             const int need = m - cnt - 1;
             const int fl = ge_ctz64(ge_ballot(acc && arank == need));
+            if (early && acc && lane > fl) {  // proposed behind the draw that completed edge m: never drawn, as far as the graph goes
+              const int a = u < v ? u : v, b = u < v ? v : u;
+              atomicAnd((unsigned long long *)&c.abits[a * W + (b >> 6)], ~(1ull << (b & 63)));
+            }
             acc = acc && lane <= fl;
             consumed = fl + 1; nacc = need + 1;
           } else {
