@@ -1372,86 +1372,88 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
             c.abits[v * W + w] = bitsw;
           }
       } else {
-        // [nx] gnm_random_graph, 64 draws per round.  A draw below ng is a node pick; picks pair up as (u, v) in
+        // [nx] gnm_random_graph.  A draw below ng is a node pick; picks pair up as (u, v) in
         // stream order; a pair is added unless u == v or the edge exists (in the matrix, or earlier in this round).
         int cnt = 0, have_u = 0, carry_u = 0;
         const uint64_t below = (1ull << lane) - 1ull;
         int rounds = 0;
+        // TWO draws per lane and round (128 raw words): a round is a chain of ~5 dependent LDS / ballot hops whatever its width, so half the
+        // rounds per attempt.  Draw j of a lane is stream position pypos + 64 j + lane; the picks of the second half follow those of the
+        // first in the u, v, u, v, ... sequence.  Every round inserts first -- the returning ds_or on the canonical (min, max) bit tells a
+        // lane that the same edge was proposed by another lane of this round, and only the keys a lane LOST on are looked at again -- and the
+        // round that reaches edge m takes the bits of the pairs behind the completing draw out again (they were absent before the round,
+        // so clearing them restores it).  (64 draws per round with an exact walk over every eligible key in the rounds that could reach
+        // edge m, rounds 1-3: 216 us of autoreset per headline step; insert-first everywhere 208.5; 128 draws 206.5.)
         for (;;) {
           // an all-zero (never seeded) or corrupted generator state draws the same pair for ever: give up loudly instead of
-          // hanging the GPU.  A healthy stream needs ~n^2 ln(n) / 64 rounds in the worst (nearly complete) case.
+          // hanging the GPU.  A healthy stream needs ~n^2 ln(n) / 128 rounds in the worst (nearly complete) case.
           if (++rounds > GE_GNM_ROUND_CAP) { failed = true; break; }
           if (pypos >= GE_MT_N) { ge_mt_twist(c.mt, lane); pypos = 0; }
-          const int p = pypos + lane;
-          const bool valid = p < GE_MT_N;
-          const uint32_t r = valid ? (ge_temper(c.mt[p]) >> shift) : (uint32_t)ng;
-          const bool pick = valid && r < (uint32_t)ng;
-          const uint64_t V = ge_ballot(pick);
-          const int gidx = ge_popc64(V & below) + have_u;            // index of this pick in the u,v,u,v,... sequence
-          const bool is_v = pick && (gidx & 1);
-          const uint64_t before = V & below;
-          const int pl = before ? 63 - (int)__builtin_clzll(before) : 0;
-          const uint32_t ur = ge_shfl_u32(r, pl);
-          const int u = before ? (int)ur : carry_u, v = (int)r;
-          bool elig = is_v && u != v && !((c.abits[u * W + (v >> 6)] >> (v & 63)) & 1ull);
-          const uint32_t key = elig ? (uint32_t)((u < v ? u : v) << 12 | (u < v ? v : u)) : 0xffffffffu;
-          const uint64_t EL = ge_ballot(elig);  // also the point after which every lane has read the pre-round matrix
-          // A round that cannot reach edge m inserts first and asks questions later: the returning ds_or on the
-          // canonical (min, max) bit tells a lane that the same edge was proposed by another lane of this round;
-          // only then (about one round in four) is the first occurrence worked out exactly.
-#ifdef GE_GNM_EXACT_LAST  // diagnostic (before / after): a round that could reach edge m walks every eligible key instead of inserting first
-          const bool early = cnt + ge_popc64(EL) < m;
-#else
-          // (EVERY round inserts first: a round that reaches edge m takes the bits of the pairs behind the completing draw out again --
-          // they were absent before the round, so clearing them restores it -- instead of working out the first occurrence of every
-          // eligible key one by one, ~16 shuffle + ballot trips on the critical path of each attempt's last rounds)
-          const bool early = true;
-#endif
-          bool lost = false;
-          if (early && elig) {
-            const int a = u < v ? u : v, b = u < v ? v : u;
-            const unsigned long long bit = 1ull << (b & 63);
-            lost = (atomicOr((unsigned long long *)&c.abits[a * W + (b >> 6)], bit) & bit) != 0;
+          const int p0 = pypos + lane, p1 = p0 + GE_WAVE;
+          const bool valid0 = p0 < GE_MT_N, valid1 = p1 < GE_MT_N;
+          const uint32_t r0 = valid0 ? (ge_temper(c.mt[p0]) >> shift) : (uint32_t)ng, r1 = valid1 ? (ge_temper(c.mt[p1]) >> shift) : (uint32_t)ng;
+          const bool pick0 = valid0 && r0 < (uint32_t)ng, pick1 = valid1 && r1 < (uint32_t)ng;
+          const uint64_t V0 = ge_ballot(pick0), V1 = ge_ballot(pick1);
+          const int n0 = ge_popc64(V0);
+          const bool is_v0 = pick0 && ((ge_popc64(V0 & below) + have_u) & 1), is_v1 = pick1 && ((n0 + ge_popc64(V1 & below) + have_u) & 1);
+          // the u of a v-pick is the pick just before it in the stream
+          const uint64_t b0 = V0 & below, b1 = V1 & below;
+          const uint32_t ur0 = ge_shfl_u32(r0, b0 ? 63 - (int)__builtin_clzll(b0) : 0), ur1 = ge_shfl_u32(r1, b1 ? 63 - (int)__builtin_clzll(b1) : 0);
+          const int last0 = V0 ? (int)ge_readlane_u32(r0, 63 - (int)__builtin_clzll(V0)) : carry_u;  // last pick before the second half
+          const int u0 = b0 ? (int)ur0 : carry_u, v0 = (int)r0, u1 = b1 ? (int)ur1 : last0, v1 = (int)r1;
+          const bool elig0 = is_v0 && u0 != v0 && !((c.abits[u0 * W + (v0 >> 6)] >> (v0 & 63)) & 1ull);
+          const bool elig1 = is_v1 && u1 != v1 && !((c.abits[u1 * W + (v1 >> 6)] >> (v1 & 63)) & 1ull);
+          const uint32_t key0 = elig0 ? (uint32_t)((u0 < v0 ? u0 : v0) << 12 | (u0 < v0 ? v0 : u0)) : 0xffffffffu;
+          const uint32_t key1 = elig1 ? (uint32_t)((u1 < v1 ? u1 : v1) << 12 | (u1 < v1 ? v1 : u1)) : 0xfffffffeu;
+          (void)ge_ballot(elig0 || elig1);  // the point after which every lane has read the pre-round matrix (lockstep on the GPU; the CPU harness runs lanes one after another)
+          bool lost0 = false, lost1 = false;
+          if (elig0) {
+            const int a = u0 < v0 ? u0 : v0, b = u0 < v0 ? v0 : u0; const unsigned long long bit = 1ull << (b & 63);
+            lost0 = (atomicOr((unsigned long long *)&c.abits[a * W + (b >> 6)], bit) & bit) != 0;
           }
-          bool dup = false;  // the same edge proposed earlier in this round
-          // (an early round only has to look at the keys a lane LOST on -- an edge proposed once has no earlier occurrence --: one or
-          // two trips where the walk over every eligible lane took ~16, each a shuffle and a ballot on the critical path of the slot)
-          const uint64_t LOST = early ? ge_ballot(lost) : EL;
-          if (LOST) {
-            for (uint64_t rem = LOST; rem;) {
-              const int l0 = ge_ctz64(rem);
-              const uint32_t k0 = ge_shfl_u32(key, l0);
-              const uint64_t same = ge_ballot(elig && key == k0);
-              if (elig && key == k0 && lane != ge_ctz64(same)) dup = true;  // every proposer but the first in stream order
-              rem &= ~same;
-            }
+          if (elig1) {  // (behind the first half's: it sees their bits)
+            const int a = u1 < v1 ? u1 : v1, b = u1 < v1 ? v1 : u1; const unsigned long long bit = 1ull << (b & 63);
+            lost1 = (atomicOr((unsigned long long *)&c.abits[a * W + (b >> 6)], bit) & bit) != 0;
           }
-          bool acc = elig && !dup;
-          uint64_t A = ge_ballot(acc);
-          int nacc = ge_popc64(A);
-          const int arank = ge_popc64(A & below);
-          const bool last_round = cnt + nacc >= m;
-          int consumed;
+          bool dup0 = false, dup1 = false;  // the same edge proposed earlier in this round
+          uint64_t rem0 = ge_ballot(lost0), rem1 = ge_ballot(lost1);
+          while (rem0 | rem1) {  // (wave-uniform) one trip per key that may have an earlier occurrence
+            const uint32_t k0 = rem0 ? ge_readlane_u32(key0, ge_ctz64(rem0)) : ge_readlane_u32(key1, ge_ctz64(rem1));
+            const uint64_t same0 = ge_ballot(elig0 && key0 == k0), same1 = ge_ballot(elig1 && key1 == k0);
+            // every proposer but the first in stream order
+            if (elig0 && key0 == k0 && lane != ge_ctz64(same0)) dup0 = true;
+            if (elig1 && key1 == k0 && (same0 != 0ull || lane != ge_ctz64(same1))) dup1 = true;
+            rem0 &= ~same0; rem1 &= ~same1;
+          }
+          bool acc0 = elig0 && !dup0, acc1 = elig1 && !dup1;
+          const uint64_t A0 = ge_ballot(acc0), A1 = ge_ballot(acc1);
+          const int na0 = ge_popc64(A0), na1 = ge_popc64(A1);
+          const int arank0 = ge_popc64(A0 & below), arank1 = na0 + ge_popc64(A1 & below);
+          const bool last_round = cnt + na0 + na1 >= m;
+          int consumed, nacc = na0 + na1;
           if (last_round) {  // the stream stops right after the draw that completed edge m
             const int need = m - cnt - 1;
-            const int fl = ge_ctz64(ge_ballot(acc && arank == need));
-            if (early && acc && lane > fl) {  // proposed behind the draw that completed edge m: never drawn, as far as the graph goes
-              const int a = u < v ? u : v, b = u < v ? v : u;
-              atomicAnd((unsigned long long *)&c.abits[a * W + (b >> 6)], ~(1ull << (b & 63)));
-            }
-            acc = acc && lane <= fl;
-            consumed = fl + 1; nacc = need + 1;
+            bool undo0 = false, undo1 = false;
+            if (need < na0) { const int fl = ge_ctz64(ge_ballot(acc0 && arank0 == need)); undo0 = acc0 && lane > fl; undo1 = acc1; acc0 = acc0 && lane <= fl; acc1 = false; consumed = fl + 1; }
+            else { const int fl = ge_ctz64(ge_ballot(acc1 && arank1 == need)); undo1 = acc1 && lane > fl; acc1 = acc1 && lane <= fl; consumed = GE_WAVE + fl + 1; }
+            if (undo0) { const int a = u0 < v0 ? u0 : v0, b = u0 < v0 ? v0 : u0; atomicAnd((unsigned long long *)&c.abits[a * W + (b >> 6)], ~(1ull << (b & 63))); }
+            if (undo1) { const int a = u1 < v1 ? u1 : v1, b = u1 < v1 ? v1 : u1; atomicAnd((unsigned long long *)&c.abits[a * W + (b >> 6)], ~(1ull << (b & 63))); }
+            nacc = need + 1;
           } else {
-            consumed = (GE_MT_N - pypos < GE_WAVE) ? (GE_MT_N - pypos) : GE_WAVE;
-            const int npick = ge_popc64(V) + have_u;
+            consumed = (GE_MT_N - pypos < 2 * GE_WAVE) ? (GE_MT_N - pypos) : 2 * GE_WAVE;
+            const int npick = n0 + ge_popc64(V1) + have_u;
             have_u = npick & 1;
-            const uint32_t lastr = ge_shfl_u32(r, V ? 63 - (int)__builtin_clzll(V) : 0);
-            if (have_u && V) carry_u = (int)lastr;  // with no pick in this round the pending u is carried unchanged
+            if (have_u && (V0 | V1)) carry_u = V1 ? (int)ge_readlane_u32(r1, 63 - (int)__builtin_clzll(V1)) : last0;  // with no pick in this round the pending u is carried unchanged
           }
-          if (acc) {  // (an early round already holds the (min, max) bit; setting it again is harmless)
-            atomicOr((unsigned long long *)&c.abits[u * W + (v >> 6)], (unsigned long long)(1ull << (v & 63)));
-            atomicOr((unsigned long long *)&c.abits[v * W + (u >> 6)], (unsigned long long)(1ull << (u & 63)));
-            c.elist[cnt + arank] = (uint32_t)u | ((uint32_t)v << 16);
+          if (acc0) {  // (the (min, max) bit is already there; setting it again is harmless)
+            atomicOr((unsigned long long *)&c.abits[u0 * W + (v0 >> 6)], (unsigned long long)(1ull << (v0 & 63)));
+            atomicOr((unsigned long long *)&c.abits[v0 * W + (u0 >> 6)], (unsigned long long)(1ull << (u0 & 63)));
+            c.elist[cnt + arank0] = (uint32_t)u0 | ((uint32_t)v0 << 16);
+          }
+          if (acc1) {
+            atomicOr((unsigned long long *)&c.abits[u1 * W + (v1 >> 6)], (unsigned long long)(1ull << (v1 & 63)));
+            atomicOr((unsigned long long *)&c.abits[v1 * W + (u1 >> 6)], (unsigned long long)(1ull << (u1 & 63)));
+            c.elist[cnt + arank1] = (uint32_t)u1 | ((uint32_t)v1 << 16);
           }
           cnt += nacc; pypos += consumed;
           ge_wave_sync();
