@@ -172,6 +172,7 @@ static int derive(const ge_config *cfg, GeParams &P, int queue_B = 0) {
   P.nowsort = (P.nocolw && n > 64) ? 1 : 0;
   ge_make_lds(P, queue_B > 0 ? queue_B : P.B);
   ge_make_ldsf(P, queue_B > 0 ? queue_B : P.B);
+  ge_tune_feat_parts(P);
   if (P.lds.total > kMaxLds || P.ldsf.total > kMaxLds) return fail(GE_E_TOOBIG, "per-env graph does not fit 160 KiB of LDS");
   return GE_OK;
 }
@@ -363,22 +364,22 @@ extern "C" int ge_create_ragged(const ge_config *cfgs, const ge_buffers *bufs, i
   memset(e->bk, 0, sizeof(e->bk));
   const int nblk_all = (int)((total + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK);
   for (int b = 0; b < GE_MAX_BUCKETS; b++) {
-    int waves = 8; bool any = false, anygen = false;
-    for (int pass = 0; pass < 2; pass++) {  // pass 0: half a CU's LDS; pass 1 (fewer than four waves fit): all of it
-      waves = 8;
-      for (const GeParams &C : e->classes) if (bucket_of(C.n) == b && C.n > 64) {
-        GeParams T = C; ge_make_ldsf(T, (int)total, 0, pass == 0 ? 160 * 1024 / 2 : 160 * 1024 - 2048);
-        if (T.ldsf.waves < waves) waves = T.ldsf.waves;
-      }
-      if (waves >= 4) break;
-    }
+    // every class takes the wave count it would choose as a uniform engine; if the bucket's widest allocation then leaves room for
+    // ONE workgroup per CU only, the smaller classes are re-derived for the whole CU (up to 16 waves: idle LDS otherwise).  The
+    // launch has the threads of the largest count; a class's surplus waves do not search (ge_features_generic_env)
+    int waves = 1; bool any = false, anygen = false;
     GeBucket &K = e->bk[b];
-    for (GeParams &C : e->classes) if (bucket_of(C.n) == b) {
-      any = true;
-      C.bucket = b;
-      ge_make_ldsf(C, (int)total, waves);
-      if (C.lds.total > K.reset_lds) K.reset_lds = C.lds.total;
-      if (C.n > 64) { anygen = true; if (C.ldsf.total > K.gen_lds) K.gen_lds = C.ldsf.total; }
+    for (int pass = 0; pass < 2; pass++) {
+      waves = 1; K.gen_lds = 0; K.reset_lds = 0;
+      for (GeParams &C : e->classes) if (bucket_of(C.n) == b) {
+        any = true;
+        C.bucket = b;
+        if (pass == 0) ge_make_ldsf(C, (int)total); else ge_make_ldsf(C, (int)total, 0, 160 * 1024 - 2048);
+        ge_tune_feat_parts(C);
+        if (C.lds.total > K.reset_lds) K.reset_lds = C.lds.total;
+        if (C.n > 64) { anygen = true; if (C.ldsf.total > K.gen_lds) K.gen_lds = C.ldsf.total; if (C.ldsf.waves > waves) waves = C.ldsf.waves; }
+      }
+      if (2 * (K.gen_lds + (nblk_all + 2) * 4) <= kMaxLds) break;  // two workgroups per CU: the classes keep their own choice
     }
     K.used = any; K.gen_used = anygen; K.gen_waves = waves;
     if (!any) continue;

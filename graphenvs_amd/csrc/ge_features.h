@@ -10,12 +10,14 @@
 #include "ge_reset.h"
 
 struct GeFctx {
-  uint64_t *abits; int *rowptr; uint16_t *colw; uint16_t *scw;
-  uint64_t *sets;                               // per wave: visited set / level being discovered (W words each)
-  double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's area)
+  uint64_t *abits; int *rowptr; uint16_t *scw;
+  uint64_t *quads; uint32_t *rq; int zq;        // Brandes role: the rows as quads of neighbour ids, {first quad | quads << 16} per node, the all-padding quad
+  uint8_t *c8;                                  // complete graph on all n nodes: the weight-code bytes (in the quads' place)
+  double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's area); coeff[n] = 0.0, the zero node
   double *bcw0; int wave_f64;                   // bcw of wave 0 and the float64 stride between waves (partial sums are combined in wave order)
   double *bc, *clos;                            // common
   double *prx, *prn, *sinv, *diff, *clus;       // node role
+  uint8_t *mark;                                // per wave: mark[w] = 1: w is a neighbour of the level just walked
   uint16_t *ord, *lvl;                          // per wave: BFS order of the current source; lvl[d] = where level d starts in it
 };
 
@@ -24,14 +26,13 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   const GeLdsF &L = P.ldsf;
   const int n = P.n, an = ((n * 8 + 15) & ~15) / 8;
   GeFctx c;
-  c.rowptr = (int *)(s + L.rowptr); c.colw = (uint16_t *)(s + L.colw);
+  c.rowptr = (int *)(s + L.rowptr); c.quads = (uint64_t *)(s + L.colw); c.c8 = (uint8_t *)(s + L.colw); c.rq = (uint32_t *)(s + L.rq); c.zq = L.zq;
   c.bc = (double *)(s + L.bc); c.clos = (double *)(s + L.clos);
   unsigned char *w = s + L.wave0 + (tid >> 6) * L.wave_stride;
-  c.sets = (uint64_t *)w;
   // (P.W <= GE_BCW_REG_W: the wave's betweenness partial sums live in registers while it runs and are handed over in delta[])
-  const int bcw_at = P.W <= GE_BCW_REG_W ? n : 3 * n;
+  const int bcw_at = P.W <= GE_BCW_REG_W ? n : 3 * n + 1;
   c.sigma = (double *)(w + L.w_sigma); c.delta = c.sigma + n; c.coeff = c.sigma + 2 * n; c.bcw = c.sigma + bcw_at;
-  c.ord = (uint16_t *)(w + L.w_ord); c.lvl = (uint16_t *)(w + L.w_lvl);
+  c.mark = (uint8_t *)(w + L.w_mark); c.ord = (uint16_t *)(w + L.w_ord); c.lvl = (uint16_t *)(w + L.w_lvl);
   c.bcw0 = (double *)(s + L.wave0 + L.w_sigma) + bcw_at; c.wave_f64 = L.wave_stride / 8;
   c.abits = (uint64_t *)(s + L.abits); c.scw = (uint16_t *)(s + L.scw);
   c.prx = (double *)(s + L.prx); c.prn = c.prx + an; c.sinv = c.prx + 2 * an; c.diff = c.prx + 3 * an; c.clus = (double *)(s + L.clus);
@@ -48,11 +49,11 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
 #endif
 #ifndef GE_FABL
 #define GE_FABL 0  // diagnostic ablation bits of the generic feature kernel (tools/variant_reset.py; the results are wrong by construction): 1 forward
-                   // push, 2 backward coefficient pass, 4 backward pull, 8 pagerank iterations; 0 when shipped
+                   // walk, 2 backward coefficient pass, 4 backward pull, 8 pagerank iterations; 0 when shipped
 #endif
 // Diagnostic build only (-DGE_STAMPS, never shipped; tools/feat_phase_clocks.py): shader-clock cycles wave 0 of slot 0's first Brandes
 // workgroup spends in the phases of the generic kernel -- [k] = cycles from stamp k to the next stamp, summed over sources and levels:
-// 0 level discovery, 1 path-count pull, 2 front update, 3 coefficients, 4 dependency pull, 5 end of a source, 6 set-up of a source;
+// 0 new level + front update, 1 forward walk, 3 coefficients, 4 dependency pull, 5 end of a source, 6 set-up of a source;
 // ge_stamp_buf[16 + k]; [24] = sources, [25] = levels
 #if defined(GE_STAMPS) && !defined(GE_EMU)
 #define GE_FSTAMP_DECL unsigned long long fs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fs_t = clock64(), fs_src = 0, fs_lev = 0; int fs_k = 7
@@ -64,80 +65,48 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
 #define GE_FSTAMP_OUT do { } while (0)
 #endif
 GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat_parts + 1 : 1; }
-// One pull of the Brandes pass over the nodes ord[k0 .. k1): a lane takes TWO nodes (k, k + 64) and walks both rows together, eight
-// entries of each per trip -- the pass is a chain of LDS round trips (order list -> row bounds -> neighbour ids -> their values), and
-// on one node with four entries per trip a level of 150 nodes cost three such chains one after the other (4 400 cycles per level
-// at n = 256, tools/feat_phase_clocks.py).  DELTA false: sigma[v] = sum of front[u] (path counts: integers, exact in any order).
-// DELTA true: delta[v] = sum of sigma[v] * coeff[w] IN ROW ORDER; an entry past the end of the row adds sigma[v] * 0.0 = +0.0.
-#ifndef GE_BP_CH
-#define GE_BP_CH 4  // row entries of a pull trip (their loads in flight together)
-#endif
-#ifndef GE_BP_U
-#define GE_BP_U 1   // rows a lane takes in a pull over a level of more than 64 nodes.  (8 entries x 2 rows was round 3's choice; measured again in
-                    // round 4, full reset per slot: n = 256 m = 1 024: 2.84 -> 2.67 us with one row, n = 400: 8.59 -> 7.94 us with one row and
-                    // four entries, n = 512: 13.8 -> 13.4 -- the kernel spills at 128 VGPRs either way, and 143 VGPRs without spills at three
-                    // waves per SIMD is 40 % slower: profiles/r04_generic_feature_variants.txt)
-#endif
-template <bool DELTA, int U>
-GE_DEV void ge_brandes_pull_u(const GeFctx &c, int k0, int k1, int lane) {
-  constexpr int CH = GE_BP_CH;
-  for (int kb = k0; kb < k1; kb += U * GE_WAVE) {
-    int v[U], e[U], r1[U]; bool on[U]; double acc[U], sv[U];
-#pragma unroll
-    // every load below is UNCONDITIONAL, from an address that is valid whatever the lane holds (k0, node 0 / row entry 0 stand in),
-    // and the value is selected afterwards: a load under a condition compiles to a branch around it with a wait behind it, one LDS
-    // round trip per entry
-    for (int u = 0; u < U; u++) { const int k = kb + u * GE_WAVE + lane; on[u] = k < k1; v[u] = (int)c.ord[on[u] ? k : k0]; }
-#pragma unroll
-    for (int u = 0; u < U; u++) { const int a = c.rowptr[v[u]], b = c.rowptr[v[u] + 1]; e[u] = on[u] ? a : 0; r1[u] = on[u] ? b : 0; sv[u] = DELTA ? c.sigma[v[u]] : 1.0; acc[u] = 0.0; }
-    while (e[0] < r1[0] || (U > 1 && e[U - 1] < r1[U - 1])) {
-      int w[U][CH]; double f[U][CH]; bool ok[U][CH];
-#pragma unroll
-      for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int j = 0; j < CH; j++) { ok[u][j] = e[u] + j < r1[u]; w[u][j] = (int)(c.colw[ok[u][j] ? e[u] + j : 0] >> 4); }
-#pragma unroll
-      for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int j = 0; j < CH; j++) { const double x = c.coeff[w[u][j]]; f[u][j] = ok[u][j] ? x : 0.0; }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-#pragma unroll
-        for (int j = 0; j < CH; j++) acc[u] += DELTA ? sv[u] * f[u][j] : f[u][j];
-        e[u] += CH;
-      }
+// One walk of the Brandes pass over the nodes ord[k0 .. k1) of a level, a lane per node, four row entries (one quad) per trip.  The
+// kernel is bound by vector-instruction issue (0.20 instructions per SIMD-cycle at four waves per SIMD, profiles/r04_generic_*), so a
+// row entry is made to cost as few instructions as it can: the row is a run of 8-byte quads of neighbour ids, padded with the zero
+// node n (coeff[n] = 0.0 always) -- no bound test, no select, one LDS read per four ids --, and a lane whose row has ended reads the
+// all-padding quad until the longest row of the trip is done.
+//  forward (BWD false): sigma[v] = sum of coeff[w] -- coeff[] holds sigma(u) on the level above and 0 everywhere else, so the
+//    test "is w one level up" is gone; the counts are integers, exact in any order -- and every neighbour is MARKED (a plain byte
+//    store: everybody writes the same 1), which is how the next level is found: no second walk over adjacency bit rows;
+//  backward (BWD true): delta[v] = sum of sigma[v] * coeff[w] IN ROW ORDER -- coeff[] holds (1 + delta(w)) / sigma(w) on the level
+//    below and 0 everywhere else; a padding entry or a neighbour that is not one level deeper adds sigma[v] * 0.0 = +0.0.
+template <bool BWD>
+GE_DEV void ge_brandes_walk(const GeFctx &c, int k0, int k1, int lane, bool store) {
+  for (int kb = k0; kb < k1; kb += GE_WAVE) {
+    const int k = kb + lane;
+    const bool on = k < k1;
+    const int v = (int)c.ord[on ? k : k0];
+    const uint32_t r = c.rq[v];
+    const uint32_t q0 = r & 0xffffu, nq = on ? (r >> 16) : 0u;
+    const double sv = BWD ? c.sigma[v] : 1.0;
+    double acc = 0.0;
+    uint64_t q = c.quads[nq ? q0 : (uint32_t)c.zq];
+    for (uint32_t i = 0; ge_ballot(i < nq) != 0ull;) {
+      i++;
+      const uint64_t qn = c.quads[i < nq ? q0 + i : (uint32_t)c.zq];  // the next quad is on its way while this one's coefficients are read
+      const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+      const int w0 = (int)(lo & 0xffffu), w1 = (int)(lo >> 16), w2 = (int)(hi & 0xffffu), w3 = (int)(hi >> 16);
+      const double f0 = c.coeff[w0], f1 = c.coeff[w1], f2 = c.coeff[w2], f3 = c.coeff[w3];
+      if (!BWD) { c.mark[w0] = 1; c.mark[w1] = 1; c.mark[w2] = 1; c.mark[w3] = 1; }
+      if (BWD) { acc += sv * f0; acc += sv * f1; acc += sv * f2; acc += sv * f3; }
+      else { acc += f0; acc += f1; acc += f2; acc += f3; }
+      q = qn;
     }
-#pragma unroll
-    for (int u = 0; u < U; u++) if (on[u]) (DELTA ? c.delta : c.sigma)[v[u]] = acc[u];
+    if (on && store) (BWD ? c.delta : c.sigma)[v] = acc;
   }
-}
-
-// OR of the adjacency bit rows of the nodes ord[lo .. hi): lane = group * Wp + word, a group takes every NG-th node, eight rows per
-// trip -- unconditional loads from addresses that are always valid, selected afterwards (see ge_brandes_pull_u) -- so the loads of
-// a trip are in flight together.  The caller combines the groups.
-GE_DEV uint64_t ge_level_rows_or(const uint16_t *ord, const uint64_t *rows, int lo, int hi, int gg, int gw, int W, int NG) {
-  uint64_t un = 0;
-  for (int k = lo + gg; k < hi; k += 8 * NG) {
-    int u[8]; uint64_t r[8]; bool ok[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { ok[j] = k + j * NG < hi && gw < W; u[j] = (int)ord[ok[j] ? k + j * NG : lo]; }
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const uint64_t x = rows[u[j] * W + (gw < W ? gw : 0)]; r[j] = ok[j] ? x : 0ull; }
-    un |= ((r[0] | r[1]) | (r[2] | r[3])) | ((r[4] | r[5]) | (r[6] | r[7]));
-  }
-  return un;
-}
-
-// (a level of at most 64 nodes -- the first and the last levels of every search -- takes one row per lane: the kernel is bound by
-// vector-instruction issue, and the second row of a lane costs its instructions whether or not it exists)
-template <bool DELTA>
-GE_DEV void ge_brandes_pull(const GeFctx &c, int k0, int k1, int lane) {
-  if (k1 - k0 <= GE_WAVE) ge_brandes_pull_u<DELTA, 1>(c, k0, k1, lane); else ge_brandes_pull_u<DELTA, GE_BP_U>(c, k0, k1, lane);
 }
 
 GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
   const int tid = ge_tid_fresh(), nthreads = ge_bdim();
-  const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = nthreads >> 6;
+  // nwaves: the waves that run searches -- as many per-wave areas as THIS geometry holds (GeLdsF.waves).  A multi-class launch has
+  // the threads of its bucket's widest wave count; the waves beyond a class's own count stage, join the barriers and do node work
+  const int lane = tid & (GE_WAVE - 1), wv = tid >> 6, nwaves = P.ldsf.waves;
+  const bool search_wave = wv < nwaves;
   const int n = P.n, W = P.W, E = P.E, F = P.F, t = P.env_type;
   const ge_buffers &G = P.buf;
   const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E;
@@ -145,107 +114,110 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   // Two roles (GeLdsF): the Brandes workgroups (a share of the BFS sources each) and the node-level workgroup (clustering, pagerank,
   // degrees); with nparts == 1 one workgroup is both.  The node role's arrays -- adjacency bit rows, sorted edge copy, pagerank
   // vectors -- overlay the Brandes role's per-wave areas when the roles are different workgroups, so a Brandes workgroup holds only
-  // what it uses (n = 256: 7 waves where 5 fitted, n = 512: 7 where 4 did) and reads the bit rows of its search from global memory
-  // (8-32 KB per slot, shared by the slot's nine workgroups: cache hits).
+  // what it uses (n = 256: 7 waves where 5 fitted, n = 512: 7 where 4 did); the searches need no adjacency bit rows at all.
   const bool node_part = nparts > 1 && part == nparts;  // this workgroup only does the node-level work
   const bool node_role = node_part || nparts == 1, brandes_role = !node_part;
-  // the slot's adjacency bit rows in HBM.  (A copy in LDS for the searches, where it costs neither a wave nor a workgroup per CU, was
-  // measured: the same cycles per source at n = 200 / 400 / 512, 26.6 -> 17 K cycles of discovery at n = 256, and config 5 lost a
-  // fifth -- dropped.)
-  const uint64_t *arows = G.adj_bits + nbase * W;
   // stage the slot's graph in LDS
-  if (node_role) for (int i = tid; i < n * W; i += nthreads) c.abits[i] = arows[i];
+  if (node_role) { const uint64_t *arows = G.adj_bits + nbase * W; for (int i = tid; i < n * W; i += nthreads) c.abits[i] = arows[i]; }
   // complete graph on all n nodes: row i holds every other node in ascending order -- entry q of the row is node q (q < i) or q + 1 --
   // and only the weight codes are staged, a byte each (scode: ascending-neighbour order)
   const bool closed = P.complete && P.ng == n;
-  uint8_t *c8 = (uint8_t *)c.colw;
-  for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = G.row_ptr[(int64_t)env * (n + 1) + v];
+  // complete graph on all n nodes (TSP config 3): every pair is adjacent, so no shortest path has an interior node
+  // (betweenness is a sum of zeros) and every BFS has one level of n-1 nodes (closeness (n-1)/(n-1) * (n-1)/(n-1))
+  const bool trivial = closed || node_part;
+  uint8_t *c8 = c.c8;
+  const int32_t *grow = G.row_ptr + (int64_t)env * (n + 1);
+  const uint16_t *gcolw = G.colw + ebase;
+  for (int v = tid; v <= n; v += nthreads) c.rowptr[v] = grow[v];
   if (closed) { for (int idx = tid; idx < E; idx += nthreads) c8[idx] = G.scode[ebase + idx]; }
-  else for (int idx = tid; idx < E; idx += nthreads) c.colw[idx] = G.colw[ebase + idx];
+  else if (brandes_role) {
+    // the rows as quads of neighbour ids.  Row v starts at quad (rowptr[v] + 3 v) / 4: consecutive starts are at least ceil(deg / 4)
+    // apart (floor(a + b) - floor(a) >= floor(b)) and the last row ends below (E + 3 n) / 4 -- a closed form instead of a scan
+    uint16_t *q16 = (uint16_t *)c.quads;
+    for (int v = tid; v < n; v += nthreads) {
+      const int r0 = grow[v], r1 = grow[v + 1], q0 = (r0 + 3 * v) >> 2, nq = (r1 - r0 + 3) >> 2;
+      c.rq[v] = (uint32_t)q0 | ((uint32_t)nq << 16);
+      for (int i = 0; i < nq; i++) {  // a quad per trip: its four global reads in flight together, one 8-byte LDS store
+        uint32_t e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int k = r0 + 4 * i + j; const uint32_t x = gcolw[k < r1 ? k : r0]; e[j] = k < r1 ? (x >> 4) : (uint32_t)n; }
+        c.quads[q0 + i] = (uint64_t)(e[0] | (e[1] << 16)) | ((uint64_t)(e[2] | (e[3] << 16)) << 32);
+      }
+    }
+    if (tid < 4) q16[4 * c.zq + tid] = (uint16_t)n;
+  }
   ge_sync();
-  // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row (complete graphs: scw IS colw)
-  if (node_role && !P.complete) for (int v = tid; v < n; v += nthreads)
+  // rows in ascending-column order (scipy canonical CSR): position by rank in the bit row
+  if (node_role && !closed) for (int v = tid; v < n; v += nthreads)
     for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) {
-      uint16_t e = c.colw[k];
+      const uint16_t e = gcolw[k];
       c.scw[c.rowptr[v] + ge_rank_below(c.abits + v * W, e >> 4)] = e;
     }
   const bool bcw_reg = W <= GE_BCW_REG_W;  // the wave's betweenness partial sums in registers: node lane + 64 j in bcr[j]
   double bcr[GE_BCW_REG_W];
 #pragma unroll
   for (int j = 0; j < GE_BCW_REG_W; j++) bcr[j] = 0.0;
-  if (brandes_role && !bcw_reg) for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
+  if (brandes_role && !bcw_reg && search_wave) for (int v = lane; v < n; v += GE_WAVE) c.bcw[v] = 0.0;
   ge_sync();
   // Brandes betweenness + closeness: one level-synchronous BFS per source, sources dealt round-robin to the waves
-  // complete graph on all n nodes (TSP config 3): every pair is adjacent, so no shortest path has an interior node
-  // (betweenness is a sum of zeros) and every BFS has one level of n-1 nodes (closeness (n-1)/(n-1) * (n-1)/(n-1))
-  const bool trivial = (P.complete && P.ng == n) || node_part;
   if (trivial && !node_part) for (int v = tid; v < n; v += nthreads) c.clos[v] = (((double)n - 1.0) / (double)(n - 1)) * (((double)n - 1.0) / (double)(n - 1));
   // One BFS per source, level by level, the nodes kept in discovery order (ord) with the start of every level (lvl): each pass
-  // touches the nodes of ONE level and their rows -- O(n + E) per source.  No atomics and no per-node level array:
-  //  * the next level is found with the adjacency BIT rows: the lanes OR the rows of the current level's nodes (groups of Wp
-  //    lanes, one word each, combined with shuffles), minus the visited set;
-  //  * path counts by pull: a node of the new level adds front[u] over its row, where front[] (kept in the coefficient array,
-  //    which the forward pass does not need) holds sigma(u) for the nodes of the current level and 0 for every other node -- the
-  //    counts are integers, exact in any order;
-  //  * dependencies by pull, as always: a node of level lev - 1 adds sigma(v) * coeff(w) over its row IN ROW ORDER; coeff[] is 0
-  //    outside level lev, so the test "is w one level deeper" is gone -- a term sigma(v) * 0.0 = +0.0 leaves the sum as it is, and
-  //    every float64 sum keeps the order (and the value) it always had.
-  const uint64_t below = (1ull << lane) - 1ull;
-  uint64_t *vis = c.sets, *nxt = vis + W;  // visited set / level being discovered (this wave's words)
-  int Wp = 1; while (Wp < W) Wp <<= 1;                  // lanes per group: lane = group * Wp + word
-  const int NG = GE_WAVE / Wp, gw = lane & (Wp - 1), gg = lane / Wp;
+  // touches the nodes of ONE level and their rows -- O(n + E) per source -- in two phases per level and direction:
+  //  forward  (a) walk the level: path counts by pull and a mark on every neighbour (ge_brandes_walk);
+  //           (b) the next level = the marked nodes without a path count yet (sigma == 0: the high word of the float64 is enough),
+  //               appended to ord by ballot / prefix count; in the same phase the front moves on: coeff[] = 0 on the level above,
+  //               = sigma on the level just walked;
+  //  backward (a) coeff[] = (1 + delta) / sigma on level lev, 0 again on level lev + 1;
+  //           (b) walk level lev - 1: delta[v] = sum of sigma[v] * coeff[w] in row order.
+  // No atomics, no per-node level array, and a neighbour's level is never tested: coeff[] is zero wherever a term must not count.
   GE_FSTAMP_DECL;
-  for (int s = part * nwaves + wv; s < n && !trivial; s += nwaves * nparts) {
+  for (int s = part * nwaves + wv; s < n && !trivial && search_wave; s += nwaves * nparts) {
     GE_FSTAMP(6);
-    for (int v = lane; v < n; v += GE_WAVE) { c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; c.coeff[v] = (v == s) ? 1.0 : 0.0; }
-    if (lane < W) vis[lane] = ((s >> 6) == lane) ? (1ull << (s & 63)) : 0ull;
-    if (lane == 0) { c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; }
+    for (int v = lane; v < n; v += GE_WAVE) { c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; c.coeff[v] = 0.0; c.mark[v] = 0; }
+    if (lane == 0) { c.coeff[n] = 0.0; c.mark[n] = 0; c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; }
     ge_wave_sync();
-    int d = 0, reach = 1, lo = 0, hi = 1; int64_t tot = 0;
+    int d = 0, reach = 1, lp = 0, lo = 0, hi = 1; int64_t tot = 0;  // level d = ord[lo .. hi), level d - 1 = ord[lp .. lo)
+    const uint32_t *sig_hi = (const uint32_t *)c.sigma + 1;
     for (;;) {
-      GE_FSTAMP(0);
-      uint64_t un = ge_level_rows_or(c.ord, arows, lo, hi, gg, gw, W, NG);
-      for (int off = Wp; off < GE_WAVE; off <<= 1) un |= ge_shfl_u64(un, lane ^ off);
-      if (lane < W) { const uint64_t nw = un & ~vis[lane]; vis[lane] |= nw; nxt[lane] = nw; }
+      GE_FSTAMP(1);
+      if (!(GE_FABL & 1)) ge_brandes_walk<false>(c, lo, hi, lane, d > 0);
       ge_wave_sync();
+      GE_FSTAMP(0);
       int found = 0;
-      for (int w0 = 0; w0 < W; w0 += 8) {  // eight words of the new level per trip (their reads in flight together)
-        uint64_t b[8];
+      for (int w0 = 0; w0 < n; w0 += 4 * GE_WAVE) {  // four chunks of 64 nodes per trip: their reads in flight together
+        uint32_t m[4], sh[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) b[j] = nxt[w0 + j < W ? w0 + j : w0];
+        for (int j = 0; j < 4; j++) { const int w = w0 + GE_WAVE * j + lane; const bool in = w < n; m[j] = c.mark[in ? w : n]; sh[j] = sig_hi[2 * (in ? w : 0)]; }
 #pragma unroll
-        for (int j = 0; j < 8; j++) if (w0 + j < W) {  // (wave-uniform)
-          if ((b[j] >> lane) & 1ull) c.ord[hi + found + ge_popc64(b[j] & below)] = (uint16_t)((w0 + j) * GE_WAVE + lane);
-          found += ge_popc64(b[j]);
+        for (int j = 0; j < 4; j++) if (w0 + GE_WAVE * j < n) {  // (wave-uniform)
+          const int w = w0 + GE_WAVE * j + lane; const bool in = w < n;
+          const bool isnew = in && m[j] != 0u && sh[j] == 0u;
+          const uint64_t b = ge_ballot(isnew);
+          if (isnew) c.ord[hi + found + ge_mbcnt(b)] = (uint16_t)w;
+          if (in) c.mark[w] = 0;
+          found += ge_popc64(b);
         }
       }
       if (!found) break;
-      ge_wave_sync();
-      GE_FSTAMP(1);
-      if (!(GE_FABL & 1)) ge_brandes_pull<false>(c, hi, hi + found, lane);
-      ge_wave_sync();
-      GE_FSTAMP(2);
-      for (int k = lo + lane; k < hi; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;                                     // the front moves on
-      for (int k = hi + lane; k < hi + found; k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = c.sigma[v]; }
-      d++; lo = hi; hi += found; reach += found; tot += (int64_t)d * found;
+      for (int k = lp + lane; k < lo; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;                           // the front moves on
+      for (int k = lo + lane; k < hi; k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = c.sigma[v]; }
+      d++; lp = lo; lo = hi; hi += found; reach += found; tot += (int64_t)d * found;
       if (lane == 0) c.lvl[d + 1] = (uint16_t)hi;
       ge_wave_sync();
     }
-    GE_FSTAMP(0);
-    for (int k = lo + lane; k < hi; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;  // coeff[] is all zero again
+    for (int k = lp + lane; k < lo; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;  // coeff[] is all zero again
     ge_wave_sync();
     for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
       GE_FSTAMP(3);
-      const int l0 = c.lvl[lev], l1 = c.lvl[lev + 1], p0 = c.lvl[lev - 1];
+      const int l0 = c.lvl[lev], l1 = c.lvl[lev + 1], l2 = lev < d ? (int)c.lvl[lev + 2] : l1, p0 = c.lvl[lev - 1];
+      for (int k = l1 + lane; k < l2; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;
       for (int k = l0 + lane; k < l1 && !(GE_FABL & 2); k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; if (!bcw_reg) c.bcw[v] += c.delta[v]; }
       ge_wave_sync();
       GE_FSTAMP(4);
-      if (!(GE_FABL & 4)) ge_brandes_pull<true>(c, p0, l0, lane);  // (+0.0 for a neighbour that is not one level deeper)
+      if (!(GE_FABL & 4)) ge_brandes_walk<true>(c, p0, l0, lane, true);  // (+0.0 for a neighbour that is not one level deeper)
       ge_wave_sync();
-      for (int k = l0 + lane; k < l1; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;
     }
     GE_FSTAMP(5);
-    ge_wave_sync();
     if (bcw_reg) {  // betweenness[v] += delta_s(v), v != s, in source order (a node the search did not reach, or of the last level, adds +0.0)
 #pragma unroll
       for (int j = 0; j < GE_BCW_REG_W; j++) { const int v = lane + GE_WAVE * j; if (j < W) bcr[j] += (v < n && v != s) ? c.delta[v] : 0.0; }
@@ -259,7 +231,7 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   }
   GE_FSTAMP(7);
   GE_FSTAMP_OUT;
-  if (bcw_reg && brandes_role) {  // (this wave's delta[] is free now: every one of its searches is over)
+  if (bcw_reg && brandes_role && search_wave) {  // (this wave's delta[] is free now: every one of its searches is over)
 #pragma unroll
     for (int j = 0; j < GE_BCW_REG_W; j++) { const int v = lane + GE_WAVE * j; if (j < W && v < n) c.bcw[v] = bcr[j]; }
   }
@@ -286,7 +258,7 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
     int64_t common = 0, dg = c.rowptr[i + 1] - c.rowptr[i];
     for (int k = c.rowptr[i]; k < c.rowptr[i + 1]; k++) {
       int j;
-      if (closed) { const int q = k - c.rowptr[i]; j = q < i ? q : q + 1; } else j = c.colw[k] >> 4;
+      if (closed) { const int q = k - c.rowptr[i]; j = q < i ? q : q + 1; } else j = c.scw[k] >> 4;
       for (int w = 0; w < W; w++) common += ge_popc64(c.abits[i * W + w] & c.abits[j * W + w]);
     }
     int64_t t8 = 8 * common, dt = 2 * dg, db = dg;

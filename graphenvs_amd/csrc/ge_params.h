@@ -45,15 +45,19 @@ struct GeLds {
 };
 
 // LDS carve of the generic structural-feature kernel
-// Two roles share one allocation.  Every workgroup stages rowptr / colw and owns bc / clos.  A Brandes workgroup (a share of the
-// slot's BFS sources) then uses `waves` per-wave areas {two node sets, sigma, delta, coeff, bcw (float64[n] each), order list, level
-// starts}; the node-level workgroup (clustering, pagerank) uses the adjacency bit rows, the sorted edge copy and its float64 arrays
-// INSTEAD -- in the same bytes (`node` == `wave0`) when the two roles are different workgroups (feat_parts > 1), behind the per-wave
-// areas when one workgroup does both.
+// Two roles share one allocation.  Every workgroup stages rowptr and owns bc / clos.  A Brandes workgroup (a share of the slot's BFS
+// sources) stages the rows as QUADS -- four neighbour ids (u16) per 8-byte word, every row padded to whole quads with the id n, the
+// "zero node" whose coefficient is always 0.0 -- and a descriptor {first quad, quads} per node, then uses `waves` per-wave areas
+// {sigma, delta, coeff (float64, coeff with the zero node's entry), bcw when the partial sums do not fit registers, mark bytes, order
+// list, level starts}; the node-level workgroup (clustering, pagerank) uses the adjacency bit rows, the sorted edge copy and its
+// float64 arrays INSTEAD -- in the same bytes (`node` == `wave0`) when the two roles are different workgroups (feat_parts > 1),
+// behind the per-wave areas when one workgroup does both.
 struct GeLdsF {
-  int rowptr, colw, bc, clos;          // common
+  int rowptr, colw, bc, clos;          // common (colw: the quads, or -- complete graph on all n nodes -- the weight-code bytes)
+  int rq;                              // u32[n] row descriptor: first quad | quads << 16
+  int zq;                              // index of the all-padding quad (a lane whose row has ended reads it)
   int wave0, wave_stride, waves;       // per-wave areas of the Brandes role
-  int w_sigma, w_ord, w_lvl;           // offsets inside a per-wave area (the node sets are at 0; delta, coeff, bcw follow sigma)
+  int w_sigma, w_mark, w_ord, w_lvl;   // offsets inside a per-wave area (delta, coeff, bcw follow sigma)
   int node, abits, scw, prx, clus;     // node role: abits, scw, then prx, prn, sinv, diff (float64[n] each), clus
   int wl;                              // node role: the 16 weights k / 10.0 by code (weighted pagerank reads one per row entry and iteration)
   int pre, total;
@@ -157,8 +161,19 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
   L.total = o;
 }
 
+// Workgroups that share one slot's BFS sources, given the waves a workgroup runs (GeLdsF.waves): every wave should get four
+// sources or more -- a workgroup stages the slot's graph before its first search -- and never more parts than the layout query
+// promised (feat_scratch is sized by them); a split geometry stays split (the LDS carve depends on it)
+static inline void ge_tune_feat_parts(GeParams &P) {
+  if (P.feat_parts <= 1) return;
+  int want = P.n / (P.ldsf.waves * 4);
+  if (want < 2) want = 2;
+  if (want < P.feat_parts) P.feat_parts = want;
+}
+
 // force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry per bucket)
-// budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU)
+// budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU; a multi-class engine passes the
+// whole CU for the classes of a bucket whose widest class leaves room for one workgroup per CU only)
 #define GE_BCW_REG_W 8  // graphs of up to 512 nodes: a wave of the generic feature kernel keeps its betweenness partial sums in registers
 static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, int budget = 160 * 1024 / 2) {
   GeLdsF &L = P.ldsf;
@@ -167,43 +182,66 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   const int n = P.n, E = P.E > 0 ? P.E : 1;
   const bool split = P.feat_parts > 1;  // the Brandes role and the node role are different workgroups
   L.rowptr = take((n + 1) * 4);
-  // (a complete graph on all n nodes keeps one weight-code BYTE per row entry, ascending-neighbour order, instead of the {neighbour,
-  // code} list: the neighbour is a closed form -- half the LDS of BASELINE config 3's slot, twice the workgroups per CU)
-  L.colw = take((P.complete && P.ng == n) ? E : E * 2);
+  // (a complete graph on all n nodes keeps one weight-code BYTE per row entry, ascending-neighbour order, instead of a neighbour list:
+  // the neighbour is a closed form and there is no search -- half the LDS of BASELINE config 3's slot, twice the workgroups per CU)
+  const bool closed = P.complete && P.ng == n;
+  const int nquads = (E + 3 * n) / 4 + 1;  // every row padded to whole quads, + the all-padding quad
+  L.zq = nquads - 1;
+  L.colw = take(closed ? E : nquads * 8);
+  L.rq = closed ? L.colw : take(n * 4);
   L.bc = take(n * 8);
   L.clos = take(n * 8);
   const int common = o;
-  // per-wave area
-  L.w_sigma = ge_align16(2 * P.W * 8);
-  L.w_ord = L.w_sigma + (P.W <= GE_BCW_REG_W ? 3 : 4) * n * 8;  // sigma, delta, coeff (+ bcw when the partial sums do not fit registers)
+  // per-wave area: sigma, delta, coeff[n + 1] (+ bcw when the partial sums do not fit registers), mark[n + 1], ord, lvl
+  L.w_sigma = 0;
+  L.w_mark = (P.W <= GE_BCW_REG_W ? 3 : 4) * n * 8 + 8;
+  L.w_ord = ge_align16(L.w_mark + n + 1);
   L.w_lvl = L.w_ord + ge_align16(2 * n);
   L.wave_stride = ge_align16(L.w_lvl + 2 * (n + 2));
   // node role
-  const int node_bytes = ge_align16(n * P.W * 8) + (P.complete ? 0 : ge_align16(E * 2)) + 5 * ge_align16(n * 8);
+  const int node_bytes = ge_align16(n * P.W * 8) + (closed ? 0 : ge_align16(E * 2)) + 5 * ge_align16(n * 8);
   // the wave count fixes the order of the float64 betweenness partial sums: it is decided from the graph geometry alone (with a
   // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
   const int fixed = common + 1024 + (split ? 0 : node_bytes);
+  // the kernel holds 128 vector registers: 16 waves per CU, as two workgroups of at most 8 or one of at most 16
+  const int whole = 160 * 1024 - 2048;
   int waves = (budget - fixed) / L.wave_stride;
-  // a graph so large that half a CU's LDS holds fewer than four waves runs one workgroup per CU with as many as fit all of it
-  if (waves < 4 && budget < 160 * 1024 - 2048) waves = (160 * 1024 - 2048 - fixed) / L.wave_stride;
-  if (waves > 8) waves = 8;
+  if (budget >= whole) { if (waves > 16) waves = 16; }
+  else {
+    if (waves > 8) waves = 8;
+    // where two workgroups of half a CU's LDS each hold fewer waves than ONE workgroup with all of it would (n > 256: a wave's
+    // area is 29 n bytes), one workgroup of up to 16 waves runs per CU -- a wave is a BFS source in flight, and at these sizes the
+    // pass is a chain of LDS round trips that only more sources in flight hide
+    int one = (whole - fixed) / L.wave_stride;
+    if (one > 16) one = 16;
+    if (one > 2 * waves) waves = one;
+  }
   if (waves < 1) waves = 1;
   if (n <= 64) waves = 1;  // only the rare fallback of the n <= 64 fast path lands here
   // complete graph on all nodes (TSP config 3): Brandes is skipped, the workgroup is the pagerank over n rows of n-1 entries --
   // one thread per pagerank row: more waves would only hold LDS
   if (P.complete && P.ng == n && n > 64) { waves = (n + 63) / 64; if (waves > 8) waves = 8; }
   if (force_waves > 0) waves = force_waves;
-  L.waves = waves;
-  L.wave0 = o;
-  const int waves_end = o + waves * L.wave_stride;
-  L.node = split ? L.wave0 : waves_end;
-  o = L.node;
-  L.abits = take(n * P.W * 8);
-  L.scw = P.complete ? L.colw : take(E * 2);  // [nx] complete_graph: the rows are already in ascending order
-  L.prx = take(4 * ge_align16(n * 8));          // prx, prn, sinv, diff
-  L.clus = take(n * 8);
-  L.wl = take(16 * 8);
-  if (o < waves_end) o = waves_end;
-  L.pre = take(((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4);
-  L.total = o;
+  const int o_common = o;
+  for (;;) {
+    o = o_common;
+    L.waves = waves;
+    L.wave0 = o;
+    const int waves_end = o + waves * L.wave_stride;
+    L.node = split ? L.wave0 : waves_end;
+    o = L.node;
+    L.abits = take(n * P.W * 8);
+    L.scw = closed ? L.colw : take(E * 2);  // rows in ascending-neighbour order ({neighbour, code}; a closed graph keeps the code bytes only)
+    L.prx = take(4 * ge_align16(n * 8));          // prx, prn, sinv, diff
+    L.clus = take(n * 8);
+    L.wl = take(16 * 8);
+    if (o < waves_end) o = waves_end;
+    const int pre_bytes = ((queue_B + GE_STEP_BLOCK - 1) / GE_STEP_BLOCK + 1) * 4;
+    L.pre = take(pre_bytes);
+    L.total = o;
+    // (an engine of so many slots that its queue prefix outgrows the nominal 1 KB: give up waves rather than fail; a multi-class
+    // launch keeps a second prefix behind the widest class's carve)
+    if (L.total + pre_bytes + 64 <= 160 * 1024 || waves == 1 || force_waves > 0) break;
+    waves--;
+  }
 }

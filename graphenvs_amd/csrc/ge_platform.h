@@ -78,6 +78,8 @@ GE_DEV uint32_t ge_uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_r
 GE_DEV double ge_u64_as_f64(uint64_t v) { return __longlong_as_double((long long)v); }
 GE_DEV uint64_t ge_f64_as_u64(double v) { return (uint64_t)__double_as_longlong(v); }
 GE_DEV int ge_popc64(uint64_t v) { return __popcll(v); }
+// set bits of the (wave-uniform) mask below this lane: v_mbcnt_lo / v_mbcnt_hi, no lane mask to build
+GE_DEV int ge_mbcnt(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? (int)__builtin_clz(v) : 32; }
 

@@ -285,6 +285,7 @@ GE_DEV uint32_t ge_readlane_u32(uint32_t v, int idx);
 GE_DEV double ge_u64_as_f64(uint64_t v) { double d; memcpy(&d, &v, 8); return d; }
 GE_DEV uint64_t ge_f64_as_u64(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
 GE_DEV int ge_popc64(uint64_t v) { return __builtin_popcountll(v); }
+GE_DEV int ge_mbcnt(uint64_t m) { return __builtin_popcountll(m & ((1ull << (ge_tid() & 63)) - 1ull)); }
 GE_DEV int ge_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 GE_DEV int ge_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
