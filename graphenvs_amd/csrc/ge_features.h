@@ -75,30 +75,47 @@ GE_HOSTDEV int ge_feat_workgroups(int feat_parts) { return feat_parts > 1 ? feat
 //    store: everybody writes the same 1), which is how the next level is found: no second walk over adjacency bit rows;
 //  backward (BWD true): delta[v] = sum of sigma[v] * coeff[w] IN ROW ORDER -- coeff[] holds (1 + delta(w)) / sigma(w) on the level
 //    below and 0 everywhere else; a padding entry or a neighbour that is not one level deeper adds sigma[v] * 0.0 = +0.0.
-template <bool BWD>
-GE_DEV void ge_brandes_walk(const GeFctx &c, int k0, int k1, int lane, bool store) {
-  for (int kb = k0; kb < k1; kb += GE_WAVE) {
-    const int k = kb + lane;
-    const bool on = k < k1;
-    const int v = (int)c.ord[on ? k : k0];
-    const uint32_t r = c.rq[v];
-    const uint32_t q0 = r & 0xffffu, nq = on ? (r >> 16) : 0u;
-    const double sv = BWD ? c.sigma[v] : 1.0;
-    double acc = 0.0;
-    uint64_t q = c.quads[nq ? q0 : (uint32_t)c.zq];
-    for (uint32_t i = 0; ge_ballot(i < nq) != 0ull;) {
+#ifndef GE_BW_TWO_ABOVE
+#define GE_BW_TWO_ABOVE 256  // graphs above this many nodes run fewer than 16 waves per CU (a wave's area is 29 n bytes of LDS)
+#endif
+#ifndef GE_BW_U
+#define GE_BW_U 1  // rows a lane takes per trip of a walk over a level of more than 64 nodes, where the geometry runs fewer than 16 waves per CU
+                   // (n > GE_BW_TWO_ABOVE).  Two rows double the reads in flight; measured (round 4, same box): n = 320: 4.02 us per slot with one row,
+                   // 4.17 with two; n = 400: 5.93 / 5.98; n = 512: 10.63 / 10.65; config 5: 19.5 M either way -- one row shipped
+#endif
+template <bool BWD, int U>
+GE_DEV void ge_brandes_walk_u(const GeFctx &c, int k0, int k1, int lane, bool store) {
+  for (int kb = k0; kb < k1; kb += U * GE_WAVE) {
+    bool on[U]; int v[U]; uint32_t q0[U], nq[U]; double sv[U], acc[U]; uint64_t q[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int k = kb + u * GE_WAVE + lane; on[u] = k < k1; v[u] = (int)c.ord[on[u] ? k : k0]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t r = c.rq[v[u]]; q0[u] = r & 0xffffu; nq[u] = on[u] ? (r >> 16) : 0u; sv[u] = BWD ? c.sigma[v[u]] : 1.0; acc[u] = 0.0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) q[u] = c.quads[nq[u] ? q0[u] : (uint32_t)c.zq];
+    for (uint32_t i = 0; ge_ballot(i < nq[0] || (U > 1 && i < nq[U - 1])) != 0ull;) {
       i++;
-      const uint64_t qn = c.quads[i < nq ? q0 + i : (uint32_t)c.zq];  // the next quad is on its way while this one's coefficients are read
-      const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
-      const int w0 = (int)(lo & 0xffffu), w1 = (int)(lo >> 16), w2 = (int)(hi & 0xffffu), w3 = (int)(hi >> 16);
-      const double f0 = c.coeff[w0], f1 = c.coeff[w1], f2 = c.coeff[w2], f3 = c.coeff[w3];
-      if (!BWD) { c.mark[w0] = 1; c.mark[w1] = 1; c.mark[w2] = 1; c.mark[w3] = 1; }
-      if (BWD) { acc += sv * f0; acc += sv * f1; acc += sv * f2; acc += sv * f3; }
-      else { acc += f0; acc += f1; acc += f2; acc += f3; }
-      q = qn;
+      uint64_t qn[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) qn[u] = c.quads[i < nq[u] ? q0[u] + i : (uint32_t)c.zq];  // the next quad is on its way while this one's coefficients are read
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t lo = (uint32_t)q[u], hi = (uint32_t)(q[u] >> 32);
+        const int w0 = (int)(lo & 0xffffu), w1 = (int)(lo >> 16), w2 = (int)(hi & 0xffffu), w3 = (int)(hi >> 16);
+        const double f0 = c.coeff[w0], f1 = c.coeff[w1], f2 = c.coeff[w2], f3 = c.coeff[w3];
+        if (!BWD) { c.mark[w0] = 1; c.mark[w1] = 1; c.mark[w2] = 1; c.mark[w3] = 1; }
+        if (BWD) { acc[u] += sv[u] * f0; acc[u] += sv[u] * f1; acc[u] += sv[u] * f2; acc[u] += sv[u] * f3; }
+        else { acc[u] += f0; acc[u] += f1; acc[u] += f2; acc[u] += f3; }
+        q[u] = qn[u];
+      }
     }
-    if (on && store) (BWD ? c.delta : c.sigma)[v] = acc;
+#pragma unroll
+    for (int u = 0; u < U; u++) if (on[u] && store) (BWD ? c.delta : c.sigma)[v[u]] = acc[u];
   }
+}
+template <bool BWD>
+GE_DEV void ge_brandes_walk(const GeFctx &c, int k0, int k1, int lane, bool store, bool two) {
+  if (GE_BW_U > 1 && two && k1 - k0 > GE_WAVE) ge_brandes_walk_u<BWD, GE_BW_U>(c, k0, k1, lane, store); else ge_brandes_walk_u<BWD, 1>(c, k0, k1, lane, store);
 }
 
 GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int nparts) {
@@ -170,17 +187,24 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   //  backward (a) coeff[] = (1 + delta) / sigma on level lev, 0 again on level lev + 1;
   //           (b) walk level lev - 1: delta[v] = sum of sigma[v] * coeff[w] in row order.
   // No atomics, no per-node level array, and a neighbour's level is never tested: coeff[] is zero wherever a term must not count.
+  const bool two = n > GE_BW_TWO_ABOVE;  // (geometries of fewer than 16 waves per CU: GE_BW_U)
   GE_FSTAMP_DECL;
   for (int s = part * nwaves + wv; s < n && !trivial && search_wave; s += nwaves * nparts) {
     GE_FSTAMP(6);
-    for (int v = lane; v < n; v += GE_WAVE) { c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; c.coeff[v] = 0.0; c.mark[v] = 0; }
-    if (lane == 0) { c.coeff[n] = 0.0; c.mark[n] = 0; c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; }
+    for (int v = lane; v < n; v += GE_WAVE) { c.sigma[v] = (v == s) ? 1.0 : 0.0; c.delta[v] = 0.0; c.coeff[v] = (v == s) ? 1.0 : 0.0; c.mark[v] = 0; }
+    // level 1 is the source's row as it stands (a simple graph: every neighbour once): no walk over level 0, no search for its marks.
+    // The walk over level 1 then finds sigma = coeff[s] = 1 for each of them and marks level 2.
+    const uint32_t rs = c.rq[s];
+    const int deg_s = c.rowptr[s + 1] - c.rowptr[s];
+    { const uint16_t *row = (const uint16_t *)(c.quads + (rs & 0xffffu)); for (int i = lane; i < deg_s; i += GE_WAVE) c.ord[1 + i] = row[i]; }
+    if (lane == 0) { c.coeff[n] = 0.0; c.mark[n] = 0; c.ord[0] = (uint16_t)s; c.lvl[0] = 0; c.lvl[1] = 1; c.lvl[2] = (uint16_t)(1 + deg_s); }
     ge_wave_sync();
-    int d = 0, reach = 1, lp = 0, lo = 0, hi = 1; int64_t tot = 0;  // level d = ord[lo .. hi), level d - 1 = ord[lp .. lo)
+    // level d = ord[lo .. hi), level d - 1 = ord[lp .. lo); coeff[] = sigma on level d - 1
+    int d = deg_s ? 1 : 0, reach = 1 + deg_s, lp = 0, lo = deg_s ? 1 : 0, hi = 1 + deg_s; int64_t tot = deg_s;
     const uint32_t *sig_hi = (const uint32_t *)c.sigma + 1;
     for (;;) {
       GE_FSTAMP(1);
-      if (!(GE_FABL & 1)) ge_brandes_walk<false>(c, lo, hi, lane, d > 0);
+      if (!(GE_FABL & 1) && d > 0) ge_brandes_walk<false>(c, lo, hi, lane, true, two);
       ge_wave_sync();
       GE_FSTAMP(0);
       int found = 0;
@@ -207,17 +231,19 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
     }
     for (int k = lp + lane; k < lo; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;  // coeff[] is all zero again
     ge_wave_sync();
-    for (int lev = d; lev >= 1; lev--) {  // backward accumulation, level by level
+    // backward accumulation, level by level.  Level 1 is where it ends: its coefficients would only serve delta[s], which nobody reads
+    for (int lev = d; lev >= 2; lev--) {
       GE_FSTAMP(3);
       const int l0 = c.lvl[lev], l1 = c.lvl[lev + 1], l2 = lev < d ? (int)c.lvl[lev + 2] : l1, p0 = c.lvl[lev - 1];
       for (int k = l1 + lane; k < l2; k += GE_WAVE) c.coeff[c.ord[k]] = 0.0;
       for (int k = l0 + lane; k < l1 && !(GE_FABL & 2); k += GE_WAVE) { const int v = c.ord[k]; c.coeff[v] = (1.0 + c.delta[v]) / c.sigma[v]; if (!bcw_reg) c.bcw[v] += c.delta[v]; }
       ge_wave_sync();
       GE_FSTAMP(4);
-      if (!(GE_FABL & 4)) ge_brandes_walk<true>(c, p0, l0, lane, true);  // (+0.0 for a neighbour that is not one level deeper)
+      if (!(GE_FABL & 4)) ge_brandes_walk<true>(c, p0, l0, lane, true, two);  // (+0.0 for a neighbour that is not one level deeper)
       ge_wave_sync();
     }
     GE_FSTAMP(5);
+    if (!bcw_reg) { const int l1 = c.lvl[2]; for (int k = 1 + lane; k < l1; k += GE_WAVE) { const int v = c.ord[k]; c.bcw[v] += c.delta[v]; } }
     if (bcw_reg) {  // betweenness[v] += delta_s(v), v != s, in source order (a node the search did not reach, or of the last level, adds +0.0)
 #pragma unroll
       for (int j = 0; j < GE_BCW_REG_W; j++) { const int v = lane + GE_WAVE * j; if (j < W) bcr[j] += (v < n && v != s) ? c.delta[v] : 0.0; }

@@ -164,9 +164,12 @@ static inline void ge_make_lds(GeParams &P, int queue_B) {
 // Workgroups that share one slot's BFS sources, given the waves a workgroup runs (GeLdsF.waves): every wave should get four
 // sources or more -- a workgroup stages the slot's graph before its first search -- and never more parts than the layout query
 // promised (feat_scratch is sized by them); a split geometry stays split (the LDS carve depends on it)
+#ifndef GE_FEAT_SRC_PER_WAVE
+#define GE_FEAT_SRC_PER_WAVE 4
+#endif
 static inline void ge_tune_feat_parts(GeParams &P) {
   if (P.feat_parts <= 1) return;
-  int want = P.n / (P.ldsf.waves * 4);
+  int want = P.n / (P.ldsf.waves * GE_FEAT_SRC_PER_WAVE);
   if (want < 2) want = 2;
   if (want < P.feat_parts) P.feat_parts = want;
 }
@@ -174,7 +177,10 @@ static inline void ge_tune_feat_parts(GeParams &P) {
 // force_waves > 0: waves per workgroup of the generic feature kernel are given (multi-class engine: one launch geometry per bucket)
 // budget: LDS bytes the wave count may be sized for (a uniform engine aims at two workgroups per CU; a multi-class engine passes the
 // whole CU for the classes of a bucket whose widest class leaves room for one workgroup per CU only)
-#define GE_BCW_REG_W 8  // graphs of up to 512 nodes: a wave of the generic feature kernel keeps its betweenness partial sums in registers
+#ifndef GE_BCW_REG_W
+#define GE_BCW_REG_W 8
+#endif
+// ^ graphs of up to 512 nodes: a wave of the generic feature kernel keeps its betweenness partial sums in registers
 static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, int budget = 160 * 1024 / 2) {
   GeLdsF &L = P.ldsf;
   int o = 0;

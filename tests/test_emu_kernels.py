@@ -37,8 +37,9 @@ def stress():
     """ONE more build of the harness with every path that only large or deep graphs take forced onto small ones: the generic feature
     kernel for slots deeper than 3 levels (-DGE_F64_LV=3), the late numpy draws of graphs above 256 nodes (-DGE_NP_EARLY_MAX=8), the
     residual-graph walks of parenting >= 2 above 512 nodes (-DGE_MAXW=1: above 64), the placement of PerishableProductDelivery above
-    128 nodes (-DGE_PPD_WIDE_ABOVE=6)"""
-    return build_emu.load(extra=["-DGE_F64_LV=3", "-DGE_NP_EARLY_MAX=8", "-DGE_MAXW=1", "-DGE_PPD_WIDE_ABOVE=6"],
+    128 nodes (-DGE_PPD_WIDE_ABOVE=6), the generic feature kernel's betweenness partial sums in LDS instead of registers, as above 512
+    nodes (-DGE_BCW_REG_W=1: above 64), and its two-rows-per-lane walks (-DGE_BW_U=2 -DGE_BW_TWO_ABOVE=64: not shipped, kept as a measured variant)"""
+    return build_emu.load(extra=["-DGE_F64_LV=3", "-DGE_NP_EARLY_MAX=8", "-DGE_MAXW=1", "-DGE_PPD_WIDE_ABOVE=6", "-DGE_BCW_REG_W=1", "-DGE_BW_TWO_ABOVE=64", "-DGE_BW_U=2"],
                           out=os.path.join(os.path.dirname(build_emu.OUT), "libgraphenvs_emu_stress.so"))
 
 
@@ -157,7 +158,8 @@ def test_emulated_fused_rollout_equals_sample_then_step(emu, env_id, kw):
 def test_emulated_feature_fast_path_falls_back_to_generic_when_too_deep(stress):
     """-DGE_F64_LV=3 forces the lane-per-source path to hand deep slots to the generic kernel."""
     lib = stress
-    for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1", "tsp_n8_m28_p1", "dc_n8_m28_complete_dist0p6"]:  # (the last two: complete graphs, whose rows the generic kernel does not stage)
+    for name in ["sp_n33_m70", "ds_n10_m20_p1", "tsp_n10_m20_p1", "tsp_n8_m28_p1", "dc_n8_m28_complete_dist0p6",  # (the last two: complete graphs, whose rows the generic kernel does not stage)
+                 "ds_n100_m300_p1"]:  # (above 64 nodes: partial sums in LDS and two rows per lane in this build)
         case = gu.load_case(name)
         gu.replay_case(case, lambda env_id, **kw: ge.GraphEnv(env_id, device="cpu", _library=lib, **kw), policies=("first",))
 

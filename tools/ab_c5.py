@@ -15,7 +15,7 @@ for rep in range(int(os.environ.get("GE_REPS", 2))):
         for env_id, extra in (("ShortestPath-v0", {}), ("MaxIndependentSet-v0", {}), ("DensestSubgraph-v0", dict(parenting=1))):
             ns = rng.integers(32, 513, per_id)
             sizes = [(int((ns == n).sum()), int(n), 3 * int(n)) for n in np.unique(ns)]
-            members.append(ge.RaggedVectorEnv(env_id, sizes, device="cuda", _library=L, **extra))
+            members.append(ge.RaggedVectorEnv(env_id, sizes, device="cuda", _library=L, prefetch=int(os.environ.get("GE_PREFETCH", 4)), **extra))
         mixed = ge.MixedVectorEnv(members)
         mixed.reset(seed=0); mixed.random_rollout(60, policy_seed=1); torch.cuda.synchronize()
         t0 = time.perf_counter(); mixed.random_rollout(steps, policy_seed=1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
