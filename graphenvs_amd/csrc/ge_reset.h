@@ -1307,6 +1307,51 @@ GE_DEV uint64_t ge_dc_search(double cutoff, int n, int s, const RP *rowptr, cons
   return reached;
 }
 
+// Write-out of the slabs that are indexed by directed edge or copied from LDS as they stand -- edge_index, edge_attr, colw, scode,
+// rev_edge, row_ptr, adj_bits, node_rec --, by BOTH waves of the workgroup (`tid` over `nthreads`): it needs nothing the first wave
+// keeps in registers, and it was 45 of the 62 us a 256-node SteinerTree slot spent writing (one wave: 32 trips of a dozen dependent
+// LDS reads each, the reverse-edge search the longest).  The reverse edge of u -> v is looked for in v's row four entries per trip,
+// every read unconditional (a search that stops at the hit is a chain of deg / 2 dependent reads).
+template <int ENV>
+GE_DEV void ge_write_edge_slabs(const GeParams &P, const GeRctx &c, int env, int tid, int nthreads) {
+  constexpr int t = ENV;
+  const ge_buffers &G = P.buf;
+  const int n = P.n, W = P.W, E = P.E;
+  const int64_t nbase = (int64_t)env * n, ebase = (int64_t)env * E, Ne = P.edge_row_stride;
+  for (int idx = tid; idx < E; idx += nthreads) {
+    int u = ge_row_of(P, c, idx), v = ge_list_nbr(P, c, idx), code = ge_list_code(P, c, idx);
+    G.edge_index[ebase + idx] = P.node_id_base + nbase + u;
+    G.edge_index[Ne + ebase + idx] = P.node_id_base + nbase + v;
+    float wv = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 1.f : (float)ge_wlut(code);
+    if (P.spatial) wv = (float)G.sw64[ebase + ge_sorted_pos_p(P, c, u, v)];
+    if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
+    else G.edge_attr[ebase + idx] = wv;
+    G.colw[ebase + idx] = (uint16_t)((v << 4) | code);
+    G.scode[ebase + idx] = P.nowsort ? (uint8_t)code : c.wsort[idx];  // (complete graph: ascending-neighbour order is insertion order)
+    if (G.rev_edge) {
+      const int r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
+      int r = -1;
+      for (int k0 = r0; k0 < r1 && r < 0; k0 += 4) {
+        int w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = (int)(c.colw[k0 + j < r1 ? k0 + j : r0] >> 4);
+#pragma unroll
+        for (int j = 3; j >= 0; j--) if (k0 + j < r1 && w[j] == u) r = k0 + j;  // (a simple graph: one hit)
+      }
+      G.rev_edge[ebase + idx] = r;
+    }
+  }
+  for (int v = tid; v <= n; v += nthreads) G.row_ptr[(int64_t)env * (n + 1) + v] = c.rowptr[v];
+  for (int i = tid; i < n * W; i += nthreads) G.adj_bits[nbase * W + i] = c.abits[i];
+  if (G.node_rec) {  // W == 1: {bit row, nibble-packed codes of the 16 smallest neighbours}
+    for (int v = tid; v < n; v += nthreads) {
+      uint64_t codes = 0; int d = c.rowptr[v + 1] - c.rowptr[v]; if (d > 16) d = 16;
+      for (int k = 0; k < d; k++) codes |= (uint64_t)(c.wsort[c.rowptr[v] + k] & 15) << (4 * k);
+      G.node_rec[(nbase + v) * 2] = c.abits[v]; G.node_rec[(nbase + v) * 2 + 1] = codes;
+    }
+  }
+}
+
 template <int ENV>
 GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, const GeRun &run, const GeInject &inj) {
   // two waves: wave 0 = python stream + everything that needs the topology; wave 1 = numpy stream (ge_numpy_wave).
@@ -1346,6 +1391,8 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
   double ppd_dt = 0.0;
   if (wv == 1) {
     if (!run.inject) { ge_numpy_wave<ENV>(P, c, run.cont ? keep_at(1) : mt_src + GE_MT_N, lane, env, pos0(1), keep_at(1)); ge_sync(); }
+    ge_sync();  // the first wave has the slot complete in LDS: both waves write the edge slabs
+    ge_write_edge_slabs<ENV>(P, c, env, tid, 2 * GE_WAVE);
     ge_sync();
     return;
   }
@@ -1727,7 +1774,6 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
   GE_STAMP(9);
   // ------------------------------------------------------------------ write the slot to HBM
   const ge_buffers &G = P.buf;
-  const int64_t Ne = P.edge_row_stride;
   uint64_t *tbits = c.bits + 3 * W;  // target set
   if (lane < W) {
     uint64_t tb = 0;
@@ -1736,7 +1782,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
     else if (t == GE_DISTRIBUTION_CENTER) for (int k = 0; k < P.n_dests; k++) { int dk = c.perm[k]; if ((dk >> 6) == lane) tb |= 1ull << (dk & 63); }
     tbits[lane] = tb;
   }
-  ge_wave_sync();
+  ge_sync();  // the slot is complete in LDS: the second wave starts on its half of the edge slabs (ge_write_edge_slabs)
   if (run.inject) {
     for (int idx = lane; idx < n * F; idx += GE_WAVE) G.x[nbase * F + idx] = inj.x[nbase * F + idx];
   } else {  // flag columns only; the five structural columns are written by the features kernel
@@ -1763,27 +1809,7 @@ GE_DEV void ge_reset_env(const GeParams &P, int env, const uint32_t *seeds, cons
       G.x[(nbase + v) * F + col] = val;
     }
   }
-  for (int idx = lane; idx < E; idx += GE_WAVE) {
-    int u = ge_row_of(P, c, idx), v = ge_list_nbr(P, c, idx), code = ge_list_code(P, c, idx);
-    G.edge_index[ebase + idx] = P.node_id_base + nbase + u;
-    G.edge_index[Ne + ebase + idx] = P.node_id_base + nbase + v;
-    float wv = (t == GE_DENSEST_SUBGRAPH || t == GE_MAX_INDEPENDENT_SET) ? 1.f : (float)ge_wlut(code);
-    if (P.spatial) wv = (float)G.sw64[ebase + ge_sorted_pos_p(P, c, u, v)];
-    if (P.Fe == 2) { G.edge_attr[(ebase + idx) * 2] = wv; G.edge_attr[(ebase + idx) * 2 + 1] = 0.f; }
-    else G.edge_attr[ebase + idx] = wv;
-    G.colw[ebase + idx] = (uint16_t)((v << 4) | code);
-    G.scode[ebase + idx] = P.nowsort ? (uint8_t)code : c.wsort[idx];  // (complete graph: ascending-neighbour order is insertion order)
-    if (G.rev_edge) { int r = -1; for (int k = c.rowptr[v]; k < c.rowptr[v + 1]; k++) if ((c.colw[k] >> 4) == u) { r = k; break; } G.rev_edge[ebase + idx] = r; }
-  }
-  for (int v = lane; v <= n; v += GE_WAVE) G.row_ptr[(int64_t)env * (n + 1) + v] = c.rowptr[v];
-  for (int i = lane; i < n * W; i += GE_WAVE) G.adj_bits[nbase * W + i] = c.abits[i];
-  if (G.node_rec) {  // W == 1: {bit row, nibble-packed codes of the 16 smallest neighbours}
-    for (int v = lane; v < n; v += GE_WAVE) {
-      uint64_t codes = 0; int d = c.rowptr[v + 1] - c.rowptr[v]; if (d > 16) d = 16;
-      for (int k = 0; k < d; k++) codes |= (uint64_t)(c.wsort[c.rowptr[v] + k] & 15) << (4 * k);
-      G.node_rec[(nbase + v) * 2] = c.abits[v]; G.node_rec[(nbase + v) * 2 + 1] = codes;
-    }
-  }
+  ge_write_edge_slabs<ENV>(P, c, env, tid, 2 * GE_WAVE);  // (this wave's half)
   // first mask (reset() -> info['mask'])
   const int A = P.A, AW = P.AW;
   const bool node_started = path_like_t;
