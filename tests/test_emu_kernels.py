@@ -285,6 +285,24 @@ def test_emulated_complete_graph_tsp_above_64_nodes_keeps_no_edge_lists_in_lds(e
     env.close()
 
 
+@pytest.mark.parametrize("env_id,kw", [("MaxIndependentSet-v0", dict(n_nodes=66, n_edges=66 * 65 // 2, weighted=False)),
+                                       ("ShortestPath-v0", dict(n_nodes=66, n_edges=66 * 65 // 2))])
+def test_emulated_complete_graph_above_64_nodes_of_an_env_without_edge_weights_in_its_pagerank(emu, env_id, kw):
+    """a complete graph on all n > 64 nodes of an env other than TSP: the generic feature kernel stages no neighbour list (the
+    neighbour of a row entry is a closed form) and the unweighted pagerank reads sinv * x of that neighbour"""
+    import oracle
+    B = 2
+    env = ge.VectorGraphEnv(env_id, B, device="cpu", _library=emu, seed_stride=1000, env_index_base=3, prefetch=0, obs_mode="flat", **kw)
+    env.reset(seed=5)
+    refs = [oracle.OracleEnv(env_id, **kw) for _ in range(B)]
+    for i, r in enumerate(refs):
+        r.reset(seed=5 + 3 + i)
+    flat = env.flat_obs().numpy()
+    for i, r in enumerate(refs):
+        assert np.array_equal(flat[i], r.obs()), i
+    env.close()
+
+
 def test_emulated_next_step_autoreset(emu):
     import oracle
     gu.check_next_step_autoreset(ge, oracle, "ShortestPath-v0", dict(n_nodes=10, n_edges=20), 5, 40, "cpu", lib=emu)
