@@ -16,7 +16,7 @@ struct GeFctx {
   double *sigma, *delta, *coeff, *bcw;          // per-wave scratch of the Brandes pass (this wave's area); coeff[n] = 0.0, the zero node
   double *bcw0; int wave_f64;                   // bcw of wave 0 and the float64 stride between waves (partial sums are combined in wave order)
   double *bc, *clos;                            // common
-  double *prx, *prn, *sinv, *diff, *clus;       // node role
+  double *prx, *prn, *sinv, *diff, *diff2, *clus;  // node role
   uint8_t *mark;                                // per wave: mark[w] = 1: w is a neighbour of the level just walked
   uint16_t *ord, *lvl;                          // per wave: BFS order of the current source; lvl[d] = where level d starts in it
 };
@@ -35,7 +35,7 @@ GE_DEV GeFctx ge_carve_f(const GeParams &P, int tid) {
   c.mark = (uint8_t *)(w + L.w_mark); c.ord = (uint16_t *)(w + L.w_ord); c.lvl = (uint16_t *)(w + L.w_lvl);
   c.bcw0 = (double *)(s + L.wave0 + L.w_sigma) + bcw_at; c.wave_f64 = L.wave_stride / 8;
   c.abits = (uint64_t *)(s + L.abits); c.scw = (uint16_t *)(s + L.scw);
-  c.prx = (double *)(s + L.prx); c.prn = c.prx + an; c.sinv = c.prx + 2 * an; c.diff = c.prx + 3 * an; c.clus = (double *)(s + L.clus);
+  c.prx = (double *)(s + L.prx); c.prn = c.prx + an; c.sinv = c.prx + 2 * an; c.diff = c.prx + 3 * an; c.diff2 = c.prx + 4 * an; c.clus = (double *)(s + L.clus);
   return c;
 }
 
@@ -309,10 +309,14 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
   }
   ge_sync();
   const double alpha = 0.85, oma = 1 - alpha, tol = 1.0e-6;
+  // ONE barrier per iteration: x and |x_new - x| are double-buffered, so an iteration writes arrays nobody is reading (a wave still
+  // summing the previous iteration's differences reads the other pair), and the copy x <- x_new is a pointer swap.  A node-level
+  // workgroup holds a whole CU's LDS while it iterates (20 % of a full reset at n = 512 with three barriers per iteration)
+  double *xc = c.prx, *xw = c.prn, *dc = c.diff, *dw = c.diff2;
   bool conv = false;
   for (int it = 0; it < ((GE_FABL & 8) ? 1 : 100) && !conv; it++) {
     double dsum = 0.0;
-    if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? c.prx[i] : dsum + c.prx[i]; first = false; } }
+    if (ndang) { bool first = true; for (int i = 0; i < n; i++) if (c.rowptr[i + 1] == c.rowptr[i]) { dsum = first ? xc[i] : dsum + xc[i]; first = false; } }
     for (int i = tid; i < n; i += nthreads) {
       double acc = 0.0;
       // GE_PR_CH row entries per trip, every load unconditional (an entry past the end of the row re-reads its first) and the terms
@@ -329,21 +333,19 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
         }
 #pragma unroll
         for (int q = 0; q < GE_PR_CH; q++) {
-          sv[q] = c.sinv[jn[q]]; xv[q] = c.prx[jn[q]];
+          sv[q] = c.sinv[jn[q]]; xv[q] = xc[jn[q]];
           wv[q] = prw ? (P.spatial ? G.sw64[ebase + (k0 + q < r1 ? k0 + q : r0)] : wl[cd[q]]) : 1.0;
         }
 #pragma unroll
         for (int q = 0; q < GE_PR_CH; q++) if (k0 + q < r1) acc += (sv[q] * wv[q]) * xv[q];
       }
       double xn = alpha * (acc + dsum * pinit) + oma * pinit;
-      c.prn[i] = xn;
-      c.diff[i] = __builtin_fabs(xn - c.prx[i]);
+      xw[i] = xn;
+      dc[i] = __builtin_fabs(xn - xc[i]);
     }
     ge_sync();
-    double err = ge_pw<5>(c.diff, n, lane);
-    ge_sync();  // every wave has read diff[] and prx[] before they are rewritten
-    for (int i = tid; i < n; i += nthreads) c.prx[i] = c.prn[i];
-    ge_sync();
+    const double err = ge_pw<5>(dc, n, lane);
+    { double *t_ = xc; xc = xw; xw = t_; t_ = dc; dc = dw; dw = t_; }
     if (err < (double)n * tol) conv = true;
   }
 
@@ -352,7 +354,7 @@ GE_DEV void ge_features_generic_env(const GeParams &P, int env, int part, int np
     float *xr = G.x + (nbase + v) * F + P.nflag;
     xr[0] = (float)(2.0 * (double)(c.rowptr[v + 1] - c.rowptr[v]));
     if (nparts == 1) { xr[1] = (float)c.bc[v]; xr[2] = (float)c.clos[v]; }
-    xr[3] = (float)c.prx[v]; xr[4] = (float)clus[v];
+    xr[3] = (float)xc[v]; xr[4] = (float)clus[v];
   }
   ge_sync();
 }

@@ -205,7 +205,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
   L.w_lvl = L.w_ord + ge_align16(2 * n);
   L.wave_stride = ge_align16(L.w_lvl + 2 * (n + 2));
   // node role
-  const int node_bytes = ge_align16(n * P.W * 8) + (closed ? 0 : ge_align16(E * 2)) + 5 * ge_align16(n * 8);
+  const int node_bytes = ge_align16(n * P.W * 8) + (closed ? 0 : ge_align16(E * 2)) + 6 * ge_align16(n * 8);
   // the wave count fixes the order of the float64 betweenness partial sums: it is decided from the graph geometry alone (with a
   // nominal 1 KB for the queue prefix), never from the batch size, so that any shard reproduces the unsharded run bit for bit
   const int fixed = common + 1024 + (split ? 0 : node_bytes);
@@ -238,7 +238,7 @@ static inline void ge_make_ldsf(GeParams &P, int queue_B, int force_waves = 0, i
     o = L.node;
     L.abits = take(n * P.W * 8);
     L.scw = closed ? L.colw : take(E * 2);  // rows in ascending-neighbour order ({neighbour, code}; a closed graph keeps the code bytes only)
-    L.prx = take(4 * ge_align16(n * 8));          // prx, prn, sinv, diff
+    L.prx = take(5 * ge_align16(n * 8));          // prx, prn, sinv, diff, diff2
     L.clus = take(n * 8);
     L.wl = take(16 * 8);
     if (o < waves_end) o = waves_end;
