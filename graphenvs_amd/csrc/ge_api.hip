@@ -536,7 +536,7 @@ static int launch_features(ge_engine *e, const GeParams &V, const GeRagged &VR, 
       }
       return (rc == GE_OK && V.feat_parts > 1) ? launch_combine(e, V, VR, as_list(run), small, stream) : rc;
     }
-    int g2 = e->gen_grid < 64 ? e->gen_grid : 64;
+    int g2 = e->gen_grid < 8 ? e->gen_grid : 8;  // (the list is normally empty and a handful of slots at most: eight workgroups dispatch in less time than 64 -- the launch is on every step's critical path)
     GE_LAUNCH(ge_k_features<false>, g2, gen_threads, e->gen_lds, stream, V, VR, as_list(run), e->gen_pre_off, -1);
     return check_launch("feature kernel (fallback list)");
   }
