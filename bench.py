@@ -36,7 +36,9 @@ PROFILE_TAGS = ("r04", "r03", "r02")
 
 # BASELINE.json configs that fit one GPU.  algo_bytes: SURVEY.md 8(d), canonical 32-bit CSR + byte mask, per env-step.
 CONFIGS = {
-    "c2": dict(env_id="ShortestPath-v0", kw=dict(n_nodes=64, n_edges=192), envs=65536, algo_bytes=200, steps=200,
+    # shards: the batch as that many independent engines on their own HIP streams (graphenvs_amd.sharded: c2 305 -> 353 M with two, 391 M with
+    # three; c4 104 -> 107 M with two; c3 313 -> 247 M, its slots all finish in the same step -- measured, profiles/r04_shards.txt)
+    "c2": dict(env_id="ShortestPath-v0", kw=dict(n_nodes=64, n_edges=192), envs=65536, algo_bytes=200, steps=200, shards=3,
                kernel="ge_k_step_path64<true, false> (fused device policy + step)",
                metric="env-steps/sec (whole node), ShortestPath-v0 n=64 m=192 batch=65536, 1/2/4/8 GPU",  # BASELINE.json's metric, verbatim
                workload="ShortestPath-v0 n_nodes=64 n_edges=192 weighted"),
@@ -44,7 +46,7 @@ CONFIGS = {
                kernel="ge_k_step<3, true> (fused device policy + step)",
                metric="env-steps/sec (whole node), TSP-v0 n=128 complete graph batch=16384 per GPU",
                workload="TSP-v0 n_nodes=128 n_edges=8128 (complete) parenting=1 weighted"),
-    "c4": dict(env_id="SteinerTree-v0", kw=dict(n_nodes=256, n_edges=1024, n_dests=8), envs=16384, algo_bytes=150, steps=400,
+    "c4": dict(env_id="SteinerTree-v0", kw=dict(n_nodes=256, n_edges=1024, n_dests=8), envs=16384, algo_bytes=150, steps=400, shards=2,
                kernel="ge_k_step_edge<2, true> (fused device policy + step, a quad of lanes per slot, incremental [B, 2m] mask)",
                metric="env-steps/sec (whole node), SteinerTree-v0 n=256 m=1024 n_dests=8 batch=16384 per GPU",
                workload="SteinerTree-v0 n_nodes=256 n_edges=1024 n_dests=8 weighted"),
@@ -190,20 +192,26 @@ def measure_uniform(ge, torch, name, cfg, args, dev, rank, world, barrier, reduc
     B = args.envs or cfg["envs"]
     steps = args.steps if args.steps > 0 else cfg["steps"]
     extra = dict(device="cpu", _library=emu) if emu is not None else dict(device=dev)
-    env = ge.make_vec(cfg["env_id"], B, env_index_base=rank * B, seed_stride=world * B,
+    shards = 1 if emu is not None else (args.shards if args.shards > 0 else cfg.get("shards", 1))
+    if shards > 1 and args.serial_shards:
+        extra = dict(extra, concurrent=False)
+    env = ge.make_vec(cfg["env_id"], B, shards=shards, env_index_base=rank * B, seed_stride=world * B,
                       prefetch=(None if args.prefetch < 0 else args.prefetch), **extra, **cfg["kw"])
+    shards = getattr(env, "shards", 1)  # (as many as the device has streams that run beside one another)
+    sharded = hasattr(env, "gather")
+    total = (lambda key: int(env.gather(key).sum())) if sharded else (lambda key: int(env.t[key].sum()))  # a per-slot counter over the whole batch
     env.reset(seed=0)
     settle = (SETTLE if name == "c2" else 2 * cfg["kw"]["n_nodes"]) if emu is None else 2
     env.random_rollout(settle, policy_seed=1)          # past the transient of the synchronised start
     env.random_rollout(args.warmup, policy_seed=1)     # the contract's W untimed steps
     barrier()
-    ep0 = int(env.t["episode"].sum())
+    ep0 = total("episode")
     t0 = time.perf_counter()
     env.random_rollout(steps, policy_seed=1)
     barrier()
     dt = reduce_max(time.perf_counter() - t0)
-    episodes = int(env.t["episode"].sum()) - ep0
-    assert int(env.t["tstep"].sum()) == B * (steps + args.warmup + settle)
+    episodes = total("episode") - ep0
+    assert total("tstep") == B * (steps + args.warmup + settle)
     value = world * B * steps / dt
     # reference window (outside the contract's timed region): 200 more steps, timed the same way -- the steady-state figure beside
     # a short driver window -- and their reset rate, to judge the timed window against
@@ -213,7 +221,7 @@ def measure_uniform(ge, torch, name, cfg, args, dev, rank, world, barrier, reduc
     env.random_rollout(REF, policy_seed=1)
     barrier()
     value_ref = B * REF / (time.perf_counter() - t1)  # this rank's slots only
-    ref_rate = (int(env.t["episode"].sum()) - ep0 - episodes) / REF
+    ref_rate = (total("episode") - ep0 - episodes) / REF
     rate = episodes / steps
     env.check_device_errors()
     out = {
@@ -223,7 +231,7 @@ def measure_uniform(ge, torch, name, cfg, args, dev, rank, world, barrier, reduc
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s, %d env slots per GPU, random valid actions on device, same-step autoreset "
                                "(seed-exact G(n,m)+features on device)" % (cfg["workload"], B),
-                   "envs_per_gpu": B, "prefetch_period": env.prefetch, "episodes_finished_per_gpu": episodes, "settle_steps": settle,
+                   "envs_per_gpu": B, "shards": shards, "prefetch_period": env.prefetch, "episodes_finished_per_gpu": episodes, "settle_steps": settle,
                    "parallelism": "batch shard x%d, no collective" % world},
         "resets_per_step": rate, "resets_per_step_reference_window": ref_rate,
         "window_stationary": bool(ref_rate > 0 and abs(rate / ref_rate - 1.0) <= 0.10),
@@ -238,25 +246,29 @@ def measure_uniform(ge, torch, name, cfg, args, dev, rank, world, barrier, reduc
     # kernel): it is calibrated on the kernel itself -- five launches in five pairs against five launches in one pair, same state,
     # right after a reset: (sum of singles - burst) / 4.  The back-to-back burst right after a full reset (step_kernel_us) is a few
     # percent faster -- warm caches, nothing between the launches -- and is reported beside it.
+    # With shards a launch of the step kernel covers ONE shard's slots: the calibration runs on shard 0 alone, and the loop's figure
+    # comes from shard 0's events while the other shards roll out beside it on their streams, as in the timed region.
+    pe = env.members[0] if sharded else env
+    Bk = pe.num_envs
     ovh = []
     for rep_ in range(7):
-        env.reset(seed=3000 + rep_)
-        singles = sum(env.timed_step_burst_raw_ms(1, policy_seed=2) for _ in range(5))
-        env.reset(seed=3000 + rep_)
-        ovh.append((singles - env.timed_step_burst_raw_ms(5, policy_seed=2)) * 1e3 / 4)
+        pe.reset(seed=3000 + rep_)
+        singles = sum(pe.timed_step_burst_raw_ms(1, policy_seed=2) for _ in range(5))
+        pe.reset(seed=3000 + rep_)
+        ovh.append((singles - pe.timed_step_burst_raw_ms(5, policy_seed=2)) * 1e3 / 4)
     pair_us = sorted(ovh)[len(ovh) // 2]
     env.reset(seed=0); env.random_rollout(settle, policy_seed=1)  # back in the steady state of the loop
     tm = env.timed_rollout(steps, policy_seed=1)
     step_us = tm["step_ms"] * 1e3 / steps - pair_us
-    burst_us = step_kernel_us(env)
+    burst_us = step_kernel_us(pe)
     algo = cfg["algo_bytes"]
-    achieved = algo * B / (step_us * 1e-6) / 1e9
+    achieved = algo * Bk / (step_us * 1e-6) / 1e9
     traffic = prof.get("step_kernel_traffic", {}).get(name)
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": prof_src,
-                       "algorithmic_bytes_per_launch": algo * B, "avg_launch_us": step_us,
+                       "algorithmic_bytes_per_launch": algo * Bk, "slots_per_launch": Bk, "avg_launch_us": step_us,
                        "avg_launch_us_method": "HIP events around every launch of the timed loop, minus what an event pair adds around this kernel (%.2f us: five launches in five pairs against five in one pair)" % pair_us,
-                       "avg_launch_us_burst": burst_us, "launch_floor_us": env.launch_floor_us(),  # an EMPTY kernel of the same grid, block and LDS
+                       "avg_launch_us_burst": burst_us, "launch_floor_us": pe.launch_floor_us(),  # an EMPTY kernel of the same grid, block and LDS
                        "kernel": cfg["kernel"]}
     out["kernel_ms_per_vector_step"] = {"step": tm["step_ms"] / steps, "autoreset": tm["reset_ms"] / steps, "policy": tm["policy_ms"] / steps}
     env.close()
@@ -272,6 +284,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="env slots per GPU (default: the config's)")
+    ap.add_argument("--shards", type=int, default=0, help="independent engines the batch of a GPU is split into, each on its own HIP stream (default: the config's; 1 = one engine)")
+    ap.add_argument("--serial-shards", action="store_true", help="diagnostic (counter collection): the shards one after the other on one stream, so that a launch's counters are its own")
     ap.add_argument("--prefetch", type=int, default=-1, help="episode prefetch: refill period in steps, 0 = regenerate in place (default: the engine's choice for the config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the 1 M-slot step-kernel roofline leg")
@@ -371,7 +385,7 @@ def main():
         # default sizes, with the step-kernel roofline and a bounded cpu_baseline of its own
         block = {}
         for name in ("c3", "c4", "c5"):
-            sub = argparse.Namespace(**vars(args)); sub.steps = 0; sub.envs = 0; sub.prefetch = -1; sub.config = name
+            sub = argparse.Namespace(**vars(args)); sub.steps = 0; sub.envs = 0; sub.prefetch = -1; sub.shards = 0; sub.config = name
             try:
                 torch.cuda.empty_cache()
                 block[name] = c5_line(sub) if name == "c5" else measure_uniform(ge, torch, name, CONFIGS[name], sub, dev, rank, world, barrier, reduce_max, prof, prof_src)

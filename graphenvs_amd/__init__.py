@@ -10,11 +10,12 @@
 from . import utils  # noqa: F401
 from .envs import GraphEnv, make  # noqa: F401
 from .ragged import MixedVectorEnv, RaggedVectorEnv  # noqa: F401
+from .sharded import ShardedVectorEnv  # noqa: F401
 from .vector_env import ENV_IDS, GraphBatch, VectorGraphEnv, make_vec  # noqa: F401
 
 name = "graphenvs_amd"
 __all__ = ["make", "make_vec", "GraphEnv", "VectorGraphEnv", "GraphBatch", "ENV_IDS", "utils",
-           "RaggedVectorEnv", "MixedVectorEnv", "register_with_gymnasium"]
+           "RaggedVectorEnv", "MixedVectorEnv", "ShardedVectorEnv", "register_with_gymnasium"]
 
 
 def register_with_gymnasium():

@@ -180,6 +180,55 @@ class RaggedVectorEnv:
             pass
 
 
+_STREAMS = {}
+
+
+def _runs_beside(a, b, device):
+    """do kernels on streams a and b overlap?  The runtime maps streams onto a handful of hardware queues, and two streams on one
+    queue run one behind the other.  Probe: a spin kernel on each, timed together against one alone."""
+    spin = getattr(torch.cuda, "_sleep", None)
+    if spin is None:
+        return True
+    cycles = 400000  # ~0.2 ms
+    def timed(streams):
+        torch.cuda.synchronize(device)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream(device)
+        t0.record(cur)
+        for st in streams:
+            st.wait_event(t0)
+            with torch.cuda.stream(st):
+                spin(cycles)
+        for st in streams:
+            cur.wait_stream(st)
+        t1.record(cur)
+        torch.cuda.synchronize(device)
+        return t0.elapsed_time(t1)
+    timed([a]); one = min(timed([a]) for _ in range(3)); both = min(timed([a, b]) for _ in range(3))
+    return both < 1.5 * one
+
+
+def _member_streams(device, want):
+    """up to `want` streams of the process (cached: every MixedVectorEnv uses the same ones) that run BESIDE one another -- a fresh
+    stream that shares a hardware queue with one already chosen is set aside and the next is tried; when eight in a row fail the
+    device has no queue left and the list ends there (profiles/r04_shards.txt: two shards on one queue 212 M env-steps/s instead of
+    353 M; five shards on a device with four queues 166 M)"""
+    dev = torch.device(device)
+    have = _STREAMS.setdefault(str(dev), [])
+    aside = _STREAMS.setdefault(str(dev) + " aside", [])
+    full = _STREAMS.setdefault(str(dev) + " full", [False])
+    while len(have) < want and not full[0]:
+        for _ in range(8):
+            cand = torch.cuda.Stream(device=dev)
+            if all(_runs_beside(e, cand, dev) for e in have):
+                have.append(cand)
+                break
+            aside.append(cand)  # (kept alive: a freed stream's queue slot would be handed out again)
+        else:
+            full[0] = True
+    return have[:want]
+
+
 class MixedVectorEnv:
     """Several env ids side by side (each a RaggedVectorEnv or VectorGraphEnv); step takes one action tensor per
     member.  Observation widths differ between ids (utils.get_env_info), so each member keeps its own PyG view.
@@ -194,7 +243,14 @@ class MixedVectorEnv:
         self.num_envs = sum(m.num_envs for m in self.members)
         dev = getattr(self.members[0], "device", None)
         self._cuda = concurrent and dev is not None and torch.device(dev).type == "cuda" and len(self.members) > 1
-        self._streams = [torch.cuda.Stream(device=m.device) for m in self.members] if self._cuda else None
+        # member k on a stream of its own -- the same streams for every MixedVectorEnv of the process, chosen so that they run beside one
+        # another (_member_streams); with fewer such streams than members, members share them round-robin
+        if self._cuda:
+            pool = _member_streams(self.members[0].device, len(self.members))
+            self._streams = [pool[k % len(pool)] for k in range(len(self.members))]
+            self.concurrent_streams = len(pool)
+        else:
+            self._streams, self.concurrent_streams = None, 1
 
     def _each(self, fn, args=None):
         """fn(member[, arg]) for every member: on the member's own stream between a fork from and a join on the current stream"""
@@ -241,8 +297,25 @@ class MixedVectorEnv:
         return self._each(lambda m: m.sample_random_actions(policy_seed))
 
     def random_rollout(self, n_steps, policy_seed=0):
-        for _ in range(int(n_steps)):  # one vector step of every member at a time: the members stay in lockstep, as with step()
-            self._each(lambda m: m.random_rollout(1, policy_seed))
+        """n_steps fused (device policy + step + autoreset) vector steps of every member.  The members are independent engines and
+        nothing is read in between, so the streams are forked ONCE, the launches of the members alternate step by step (the host
+        enqueues far ahead of the GPU: a member enqueued whole would run alone until the next one's launches arrive) and the caller's
+        stream joins ONCE at the end -- no event between streams per step, and no member waits for the regeneration round of another."""
+        n_steps = int(n_steps)
+        if not self._cuda:
+            for m in self.members:
+                m.random_rollout(n_steps, policy_seed)
+            return
+        cur = torch.cuda.current_stream(self.members[0].device)
+        fork = cur.record_event()
+        for st in self._streams:
+            st.wait_event(fork)
+        for _ in range(n_steps):
+            for m, st in zip(self.members, self._streams):
+                with torch.cuda.stream(st):
+                    m.random_rollout(1, policy_seed)
+        for st in self._streams:
+            cur.wait_stream(st)
 
     def close(self):
         for m in self.members:

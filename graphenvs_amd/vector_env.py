@@ -576,5 +576,9 @@ class VectorGraphEnv(_VectorBase):
         return (ei - off).permute(1, 2, 0).contiguous()
 
 
-def make_vec(env_id, num_envs, **kwargs):
+def make_vec(env_id, num_envs, shards=1, **kwargs):
+    """``shards`` > 1: the batch as that many independent engines on their own HIP streams (graphenvs_amd.sharded.ShardedVectorEnv)"""
+    if shards is not None and int(shards) > 1:
+        from .sharded import ShardedVectorEnv
+        return ShardedVectorEnv(env_id, num_envs, shards=int(shards), **kwargs)
     return VectorGraphEnv(env_id, num_envs, **kwargs)

@@ -207,3 +207,24 @@ def check_prefetch_state_dict_next_step(ge, device, lib):
         _same_live(b, ref, k)
     assert int(b.t["episode"].min()) > 0
     a.close(); b.close(); ref.close()
+
+
+def check_shards_equal_one_engine(ge, device, env_id="ShortestPath-v0", kw=None, B=10, K=25, library=None):
+    """the batch as 1 and as 3 independent engines (make_vec(shards=)): the same slots, bit for bit, after a reset and a rollout of the
+    device policy with autoreset -- per-slot tensors gathered in slot order, the observations shard after shard"""
+    import torch
+    kw = dict(kw or dict(n_nodes=10, n_edges=20))
+    extra = dict(device=device, _library=library) if library is not None else dict(device=device)
+    one = ge.make_vec(env_id, B, prefetch=0, **extra, **kw)
+    many = ge.make_vec(env_id, B, shards=3, prefetch=0, **extra, **kw)
+    assert [m.num_envs for m in many.members] == [B // 3 + (1 if k < B % 3 else 0) for k in range(3)] and many.num_envs == B
+    one.reset(seed=7); many.reset(seed=7)
+    for round_ in range(2):
+        for key in ("episode", "tstep", "seed", "reward", "terminated", "cost", "solved"):
+            assert torch.equal(one.t[key], many.gather(key)), (round_, key)
+        assert torch.equal(one.t["x"], torch.cat([m.t["x"] for m in many.members])), round_
+        assert torch.equal(one.t["mask"], torch.cat([m.t["mask"] for m in many.members])), round_
+        one.random_rollout(K, policy_seed=5); many.random_rollout(K, policy_seed=5)
+    assert int(one.t["episode"].sum()) > 0
+    many.check_device_errors()
+    one.close(); many.close()

@@ -303,6 +303,10 @@ def test_emulated_complete_graph_above_64_nodes_of_an_env_without_edge_weights_i
     env.close()
 
 
+def test_emulated_shards_equal_one_engine(emu):
+    hc.check_shards_equal_one_engine(ge, "cpu", library=emu)
+
+
 def test_emulated_next_step_autoreset(emu):
     import oracle
     gu.check_next_step_autoreset(ge, oracle, "ShortestPath-v0", dict(n_nodes=10, n_edges=20), 5, 40, "cpu", lib=emu)

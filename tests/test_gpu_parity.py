@@ -650,3 +650,12 @@ def test_spatial_tsp_fixture_sits_on_the_pow_boundary():
     case = gu.load_case("tsp_n12_m30_p1_spatial_pow2")
     st = gu.replay_case(case, lambda env_id, **kw: _ge().GraphEnv(env_id, **kw))
     assert st["inexact_rewards"] > 0 and st["steps"] > 30
+
+
+@pytest.mark.gpu
+def test_shards_equal_one_engine():
+    """make_vec(shards=3): three engines on their own HIP streams hold the same slots as one engine, bit for bit (graphenvs_amd.sharded)"""
+    import host_checks as hc
+    ge = _ge()
+    hc.check_shards_equal_one_engine(ge, "cuda", kw=dict(n_nodes=64, n_edges=192), B=100, K=40)
+    hc.check_shards_equal_one_engine(ge, "cuda", env_id="SteinerTree-v0", kw=dict(n_nodes=70, n_edges=200, n_dests=4), B=10, K=60)

@@ -5,6 +5,7 @@ TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}_prof; mkdir -p $O
 # what was measured, and when: bench.py only quotes counter evidence whose source hash is that of the library it runs
 python3 -c "import sys, datetime; sys.path.insert(0, '$R'); from graphenvs_amd import _lib; print(_lib.source_hash()); print(datetime.datetime.now(datetime.timezone.utc).strftime('%Y-%m-%dT%H:%MZ'))" > $O/source_hash.txt
+export PMC_EXTRA=--serial-shards
 bash $R/tools/pmc_sq_passes.sh ${TAG}_prof/c2 bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-1m --no-configs > $O/c2_passes.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 export GE_B=1048576 GE_REPS=3

@@ -1,4 +1,6 @@
 # SQ / TCC counter passes (separate rocprofv3 --pmc runs, kernel-trace only) + a kernel-trace --stats run over one command.
+# PMC_EXTRA: arguments for the counter passes only (bench.py --serial-shards: a launch's counters are device-wide while it runs, so the
+# shards of a sharded engine are run one after the other there; the kernel trace is of the command as given)
 # usage (GPU box): bash tools/pmc_sq_passes.sh <tag> <python script and args ...>     -> gpurun_out/<tag>/{summary.json,kernel_medians.txt,kernel_stats.csv}
 set -e
 TAG=$1; shift
@@ -9,7 +11,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace -d $O/p$i --output-format csv -- python3 $R/"$@" > $O/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace -d $O/p$i --output-format csv -- python3 $R/"$@" $PMC_EXTRA > $O/p$i.log 2>&1 || echo "pass $i failed"
   echo "pass $i done"
 done
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/"$@" > $O/trace.out 2> $O/trace.log || echo "trace failed"

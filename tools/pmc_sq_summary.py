@@ -11,7 +11,10 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), re
         key = (k, r["Counter_Name"], r["Dispatch_Id"])
         per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
     for (k, c, _), v in per.items(): acc.setdefault(k, {}).setdefault(c, []).append(v)
-for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+# durations from the FIRST counter pass (its kernel trace): the passes may run a serialized variant of the command (PMC_EXTRA of
+# tools/pmc_sq_passes.sh: the shards of a sharded engine one after the other), and a launch's cycles must be those of the run its
+# counters come from; kernel_medians.txt beside this file is the trace of the command as given
+for f in (glob.glob(os.path.join(root, "p1", "**", "*_kernel_trace.csv"), recursive=True) or glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "ge_k" in k: dur.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
