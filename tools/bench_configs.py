@@ -45,15 +45,17 @@ for name in (sys.argv[1:] or ["c3", "c4"]):
         bench_c5(ids={"c5": (0, 1, 2), "c5sp": (0,), "c5mis": (1,), "c5ds": (2,)}[name])
         continue
     name, _, pf = name.partition("@")  # name@period: with episode prefetch (spares), refill every `period` steps
+    name, _, sh = name.partition("/")  # name/S: as S shards (graphenvs_amd.sharded)
     env_id, kw, B, K = CONFIGS[name]
-    env = ge.make_vec(env_id, B, prefetch=(int(pf) if pf else None), **kw)
+    env = ge.make_vec(env_id, B, shards=(int(sh) if sh else 1), prefetch=(int(pf) if pf else None), **kw)
+    eps = (lambda: int(env.gather("episode").sum())) if hasattr(env, "gather") else (lambda: int(env.t["episode"].sum()))
     # the first launch of a kernel instantiation pays its code-object load (round 1's 106 ms "full reset" of the first config in the
     # list was that): one untimed reset first, the timed one after it
     env.reset(seed=1); torch.cuda.synchronize()
     t0 = time.perf_counter(); env.reset(seed=0); torch.cuda.synchronize(); t_reset = time.perf_counter() - t0
     env.random_rollout(10, policy_seed=1); torch.cuda.synchronize()
-    ep0 = int(env.t["episode"].sum())
+    ep0 = eps()
     t0 = time.perf_counter(); env.random_rollout(K, policy_seed=1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(config=name, prefetch=env.prefetch, env=env_id, kwargs=kw, envs=B, steps=K, env_steps_per_s=B * K / dt, ms_per_vector_step=dt * 1e3 / K,
-                          episodes=int(env.t["episode"].sum()) - ep0, full_reset_ms=t_reset * 1e3)), flush=True)
+    print(json.dumps(dict(config=name, shards=getattr(env, "shards", 1), prefetch=env.prefetch, env=env_id, kwargs=kw, envs=B, steps=K, env_steps_per_s=B * K / dt, ms_per_vector_step=dt * 1e3 / K,
+                          episodes=eps() - ep0, full_reset_ms=t_reset * 1e3)), flush=True)
     env.close(); del env; torch.cuda.empty_cache()

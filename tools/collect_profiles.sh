@@ -20,5 +20,5 @@ for cfg in c3 c4; do
 done
 cd $R
 timeout -k 10 400 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-timeout -k 10 400 python3 tools/bench_configs.py mis ds mc dc ppd > $O/other_configs.jsonl 2> $O/other_configs.err
+timeout -k 10 400 python3 tools/bench_configs.py mis ds/3 mc/2 dc/3 ppd > $O/other_configs.jsonl 2> $O/other_configs.err
 cat $O/c2/kernel_medians.txt; cut -c1-200 $O/bench_c2.json; cat $O/other_configs.jsonl
