@@ -568,10 +568,12 @@ GE_DEV void ge_f64_walk_env(const GeParams &P, int env, int *ovf_flag, int32_t *
     for (int i = lane; i < GE_F64_SB * GE_F64_SS; i += GE_WAVE) S[i] = 0.0;
     ge_wave_sync();
     if (o == 0 && src) sigrow[s] = 1;
+    // level 1 is the source's neighbours: one path each, no pull (a trip of the loop below for every search otherwise)
+    { const int lo = lstrow[1], hi = Dw >= 1 ? (int)lstrow[2] : lo; for (int k = lo + o; k < hi; k += 8) sigrow[ordrow[k]] = 1; }  // (Dw == 0: no search of this wave has a level 1, lstrow[2] was not written)
     const bool deep = ge_ballot(ovf) != 0ull;  // the slot goes to the generic kernel: skip the pulls (their level arrays would overrun)
     ge_wave_sync();
     // ---- (2) path counts: sigma(v) = sum of sigma(u) over v's neighbours u in the level above
-    for (int d = 1; d <= Dw && !deep && !(GE_F64_ABL & 1); d++) {
+    for (int d = 2; d <= Dw && !deep && !(GE_F64_ABL & 1); d++) {
       const int lo = lstrow[d], hi = lstrow[d + 1];
       const uint64_t prev = lvl[(d - 1) * GE_F64_SB + sl];
       for (int k = lo + o; ge_ballot(k < hi) != 0ull; k += 8) {
