@@ -226,5 +226,13 @@ def check_shards_equal_one_engine(ge, device, env_id="ShortestPath-v0", kw=None,
         assert torch.equal(one.t["mask"], torch.cat([m.t["mask"] for m in many.members])), round_
         one.random_rollout(K, policy_seed=5); many.random_rollout(K, policy_seed=5)
     assert int(one.t["episode"].sum()) > 0
+    # step(): one action tensor per shard in, one entry per shard out (streams forked and joined per call)
+    a1 = one.sample_random_actions(policy_seed=9).clone()
+    am = many.sample_random_actions(policy_seed=9)
+    assert torch.equal(a1, torch.cat(am))
+    o1 = one.step(a1)
+    om = many.step([a.clone() for a in am])
+    assert torch.equal(o1[1], torch.cat(om[1])) and torch.equal(o1[2], torch.cat(om[2]))  # reward, terminated
+    assert torch.equal(one.t["x"], torch.cat([m.t["x"] for m in many.members]))
     many.check_device_errors()
     one.close(); many.close()
