@@ -193,6 +193,7 @@ def measure_uniform(ge, torch, name, cfg, args, dev, rank, world, barrier, reduc
     steps = args.steps if args.steps > 0 else cfg["steps"]
     extra = dict(device="cpu", _library=emu) if emu is not None else dict(device=dev)
     shards = 1 if emu is not None else (args.shards if args.shards > 0 else cfg.get("shards", 1))
+    extra0 = dict(extra)
     if shards > 1 and args.serial_shards:
         extra = dict(extra, concurrent=False)
     env = ge.make_vec(cfg["env_id"], B, shards=shards, env_index_base=rank * B, seed_stride=world * B,
@@ -272,6 +273,14 @@ def measure_uniform(ge, torch, name, cfg, args, dev, rank, world, barrier, reduc
                        "kernel": cfg["kernel"]}
     out["kernel_ms_per_vector_step"] = {"step": tm["step_ms"] / steps, "autoreset": tm["reset_ms"] / steps, "policy": tm["policy_ms"] / steps}
     env.close()
+    if sharded:  # beside the shard's launch in the loop: the same kernel over the WHOLE batch in one launch, alone (a burst right after a reset)
+        whole = ge.make_vec(cfg["env_id"], B, env_index_base=rank * B, seed_stride=world * B, prefetch=0, **extra0, **cfg["kw"])
+        whole.reset(seed=0)
+        w_us = step_kernel_us(whole)
+        out["roofline"]["one_engine_launch"] = {"slots_per_launch": B, "algorithmic_bytes_per_launch": algo * B, "avg_launch_us_burst": w_us,
+                                                "achieved": algo * B / (w_us * 1e-6) / 1e9, "frac": algo * B / (w_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                "note": "one engine's launch over the whole batch, nothing beside it; the loop's launches cover one shard and share the chip with the other shards' kernels"}
+        whole.close()
     return out
 
 
