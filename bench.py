@@ -52,10 +52,10 @@ CONFIGS = {
                workload="SteinerTree-v0 n_nodes=256 n_edges=1024 n_dests=8 weighted"),
     # mixed ragged batch: three multi-class engines (one per env id) side by side; algo_bytes per member at the mean size n = 272, m = 3n
     "c5": dict(members=(("ShortestPath-v0", {}, 200), ("MaxIndependentSet-v0", {}, 4 + 4 + 272), ("DensestSubgraph-v0", dict(parenting=1), 24 + 272 + 40)),
-               envs=3 * 16384, steps=100,
+               envs=3 * 16384, steps=100, split={"ShortestPath-v0": 2},
                kernel="ge_k_step<ENV, true, RAGGED> (thread per slot, class looked up per slot), one launch per env id",
                metric="env-steps/sec (whole node), mixed {ShortestPath, MaxIndependentSet, DensestSubgraph} ragged n in [32,512], m = 3n, 3 x 16384 slots per GPU",
-               workload="mixed ragged: 16 384 slots per env id, n ~ U{32..512} (481 size classes per id), m = 3n, one multi-class engine per id"),
+               workload="mixed ragged: 16 384 slots per env id, n ~ U{32..512} (481 size classes per id), m = 3n, one multi-class engine per id (ShortestPath: two, the slots of every size dealt alternately)"),
 }
 
 
@@ -148,16 +148,26 @@ def make_c5(ge, cfg, dev, slots_per_id, rank, world):
     import numpy as np
     rng = np.random.default_rng(0)
     members = []
-    for env_id, extra, _ in cfg["members"]:
+    # An env id whose regenerations are the longest (ShortestPath: the n x n numpy draws of its weighted graphs) runs as two engines --
+    # the slots of every size dealt alternately -- so that one half's latency-bound graph kernel overlaps the other's feature kernel:
+    # four engines on the device's four hardware queues (profiles/r04_shards.txt: 25.4 -> 28.5 M; five engines 22.3 M)
+    labels = []
+    for env_id, extra, algo in cfg["members"]:
         ns = rng.integers(32, 513, slots_per_id)
-        sizes = [(int((ns == n).sum()), int(n), 3 * int(n)) for n in np.unique(ns)]
-        members.append(ge.RaggedVectorEnv(env_id, sizes, device=dev, env_index_base=rank * slots_per_id, seed_stride=world * slots_per_id, **extra))
-    return ge.MixedVectorEnv(members), members
+        parts = cfg.get("split", {}).get(env_id, 1)
+        off = 0
+        for k in range(parts):
+            sub = ns[k::parts]
+            sizes = [(int((sub == n).sum()), int(n), 3 * int(n)) for n in np.unique(sub)]
+            members.append(ge.RaggedVectorEnv(env_id, sizes, device=dev, env_index_base=rank * slots_per_id + off, seed_stride=world * slots_per_id, **extra))
+            labels.append((env_id + (" [%d/%d]" % (k + 1, parts) if parts > 1 else ""), extra, algo))
+            off += len(sub)
+    return ge.MixedVectorEnv(members), members, labels
 
 
 def measure_c5(ge, torch, cfg, args, dev, rank, world, barrier, prof):
     per_id = (args.envs // 3) if args.envs else cfg["envs"] // 3
-    mixed, members = make_c5(ge, cfg, dev, per_id, rank, world)
+    mixed, members, labels = make_c5(ge, cfg, dev, per_id, rank, world)
     B = mixed.num_envs
     steps = args.steps if args.steps > 0 else cfg["steps"]
     eps = lambda: sum(int(m.g["episode"].sum()) for m in members)
@@ -173,7 +183,7 @@ def measure_c5(ge, torch, cfg, args, dev, rank, world, barrier, prof):
     episodes = eps() - ep0
     # step kernel of every member inside its own loop (HIP events on the launch stream)
     rl = []
-    for m, (env_id, _, algo) in zip(members, cfg["members"]):
+    for m, (env_id, _, algo) in zip(members, labels):
         tm = m.timed_rollout(30, policy_seed=1)
         us = tm["step_ms"] * 1e3 / 30
         ach = algo * m.num_envs / (us * 1e-6) / 1e9
@@ -365,7 +375,7 @@ def main():
         return {"metric": c["metric"], "value": world * B * steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": sub_args.warmup,
                 "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": c["workload"], "envs_per_gpu": B, "prefetch_period": pf, "episodes_finished_per_gpu": episodes, "settle_steps": settle,
-                           "parallelism": "batch shard x%d, no collective" % world, "launch_sequences_per_step": 3},
+                           "parallelism": "batch shard x%d, no collective" % world, "launch_sequences_per_step": len(rl), "engines": [r["member"] for r in rl]},
                 "resets_per_step": episodes / steps,
                 "roofline": max(rl, key=lambda r: r["avg_launch_us"]), "roofline_members": rl}
 
